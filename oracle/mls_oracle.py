@@ -1,0 +1,129 @@
+"""ORACLE — test infrastructure, not product code.
+
+CPU restatement of the reference algorithm for the MLS hot path
+(zignal v0.6.0, `zignal/measure/mls.py`). Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import this module; the shipped package
+`zignal_amd` never does (tests/test_boundary_cpu.py greps for that).
+
+Parity status: PINNED. tests/test_oracle_golden.py checks every function here
+against fixtures in tests/golden/ that were produced by importing the real
+reference in the build container (tests/golden/make_golden.py), plus the one
+known-answer example the reference itself carries (mls.py:179-205).
+
+The arithmetic is deliberately the reference's, step for step (a per-bit shift
+register, numpy's mean over periods, an FFT convolution with the flipped
+stimulus, fold, divide by L) so that timing this module on the GPU box's host
+cores is an honest stand-in for timing the reference there. `scipy.signal.
+fftconvolve` and `numpy.average` are the same third-party routines the reference
+calls (scipy is un-pinned in the reference's setup.py:20-25).
+"""
+from collections import deque
+
+import numpy as np
+import scipy.signal
+
+
+def check_ctor_args(N, taps):
+    """Argument checks of `_MLS_base.__init__` (mls.py:64-68): AssertionError each."""
+    assert N is not None, "Please specify MLS order"
+    assert taps is not None, "Please specify feedback taps"
+    assert isinstance(taps, (tuple, list))
+    assert len(taps) != 0, "taps are empty!"
+
+
+def bit_stream(N, taps):
+    """Endless LFSR bit generator (mls.py:91-115).
+
+    Register = N cells, all zero except the newest one; each step XORs the cells
+    `tap` steps back (cell index N - tap), pushes the result in as the newest cell
+    and emits it.
+    """
+    reg = deque([0] * (N - 1) + [1], maxlen=N)
+    while True:
+        b = 0
+        for t in taps:
+            b ^= reg[N - t]
+        reg.append(b)
+        yield b
+
+
+def chunk_stream(N, taps, chunk=1024):
+    """(chunk, 1) int64 blocks of consecutive bits, continuing across the period
+    boundary (mls.py:117-128)."""
+    bits = bit_stream(N, taps)
+    while True:
+        block = np.zeros((chunk, 1), dtype=np.int64)
+        for i in range(chunk):
+            block[i] = next(bits)
+        yield block
+
+
+def sample_stream(N, taps, chunk=1024):
+    """(chunk, 1) float64 blocks; bit 0 -> +1.0, bit 1 -> -1.0 (mls.py:130-152)."""
+    for block in chunk_stream(N, taps, chunk):
+        yield (-(block * 2 - 1)).astype(np.float64)
+
+
+def full_sequence(N, taps, repeats=1):
+    """One freshly generated period tiled `repeats` times -> (repeats*L, 1) float64
+    (mls.py:154-167)."""
+    L = (1 << N) - 1
+    one = next(sample_stream(N, taps, chunk=L))
+    return np.tile(one.T, repeats).T
+
+
+def trim_and_average(x, L):
+    """Drop the first period, mean over the rest -> (L, 1) (mls.py:258-313).
+
+    `reshape` raises ValueError when len(x) is not a multiple of L or x has more
+    than one channel — same as the reference (mls.py:298).
+    """
+    kept = x[L:]
+    periods = len(kept) // L
+    rows = kept.reshape((periods, L))
+    return np.expand_dims(np.average(rows, axis=0), axis=1)
+
+
+def xcorr_circular(avg, ref):
+    """Circular cross-correlation of one averaged period with the stimulus `ref`
+    ((L,1) each) -> (L,1) float64 (mls.py:169-256): linear correlation through
+    `fftconvolve` with the flipped stimulus, negative lags folded onto the
+    positive ones, lag 0 first, divided by L."""
+    L = ref.shape[0]
+    lin = scipy.signal.fftconvolve(np.flipud(ref), avg)     # (2L-1, 1), lag 0 at index L-1
+    lin[L:] = lin[L:] + lin[:L - 1]                         # lag m gets lag m-L added
+    out = lin[L - 1:]
+    out[:] = out / L
+    return out
+
+
+def get_impulse(N, taps, x, ref=None):
+    """`_MLS_base.get_impulse` (mls.py:315-328). `ref` lets a caller reuse one
+    generated period (the reference regenerates it on every call, mls.py:207)."""
+    L = (1 << N) - 1
+    assert isinstance(x, np.ndarray)
+    assert len(x) > L, "The first sequence will be thrown away"
+    avg = trim_and_average(x, L)
+    if ref is None:
+        ref = full_sequence(N, taps, 1)
+    return xcorr_circular(avg, ref)
+
+
+def packed_bits(N, taps):
+    """LSB-first packed bits of one period (the KAT packing)."""
+    s = full_sequence(N, taps, 1)[:, 0]
+    return np.packbits(((1.0 - s) / 2.0).astype(np.uint8), bitorder="little")
+
+
+# ---------------------------------------------------------------------------
+# Independent cross-checks used by the tests (not part of the reference's path)
+# ---------------------------------------------------------------------------
+def xcorr_by_definition(avg, ref):
+    """h[m] = (1/L) sum_i ref[i]*avg[(i+m) mod L], O(L^2); small L only."""
+    a = np.asarray(avg, dtype=np.float64).reshape(-1)
+    r = np.asarray(ref, dtype=np.float64).reshape(-1)
+    L = r.shape[0]
+    out = np.empty(L)
+    for m in range(L):
+        out[m] = np.dot(r, np.roll(a, -m)) / L
+    return out.reshape(-1, 1)

@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REAL reference
+(/root/reference, zignal v0.6.0) on inputs this repository owns.
+
+Runs only in the build container: it refuses to start without /root/reference
+and nothing under tests/, bench.py or the package imports it. Fixtures are data
+(inputs, outputs, digests); no reference source is copied.
+
+Import recipe is the one recorded in SURVEY.md §8(c): the reference's
+`audio.py` imports the (absent) `samplerate` package at module level although
+the MLS path never calls it, so an empty module object is registered first.
+
+    python tests/golden/make_golden.py            # everything (≈6 min)
+    python tests/golden/make_golden.py --quick    # skip N >= 21 sequence KATs and N=24 IR
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+if not os.path.isdir(os.path.join(REF, "zignal")):
+    sys.exit("make_golden.py needs the reference checkout at /root/reference")
+
+sys.path.insert(0, HERE)
+sys.path.insert(0, REF)
+sys.modules.setdefault("samplerate", types.ModuleType("samplerate"))
+os.environ.setdefault("MPLBACKEND", "Agg")
+warnings.simplefilter("ignore")
+
+import matplotlib  # noqa: E402
+
+matplotlib.use("Agg")
+
+import zignal  # noqa: E402  (the reference)
+from zignal.measure.mls import MLS, MLS_simple, TAPS, _MLS_base, get_random_taps  # noqa: E402
+
+import inputs  # noqa: E402  (ours)
+
+
+def write_json(name, obj):
+    with open(os.path.join(HERE, name), "w") as f:
+        json.dump(obj, f, indent=1, sort_keys=True)
+        f.write("\n")
+
+
+# --------------------------------------------------------------------------- taps
+def dump_taps():
+    table = {str(N): [list(t) for t in TAPS[N]] for N in sorted(TAPS)}
+    txt = json.dumps(table, separators=(",", ":"), sort_keys=True)
+    with open(os.path.join(HERE, "taps.json"), "w") as f:
+        f.write(txt + "\n")
+    # the package ships the same table as data (zignal_amd/measure/taps.json)
+    with open(os.path.join(REPO, "zignal_amd", "measure", "taps.json"), "w") as f:
+        f.write(txt + "\n")
+    print("taps: %d orders, %d tap sets" % (len(table), sum(len(v) for v in table.values())))
+
+
+# --------------------------------------------------------------------------- sequence KATs
+def seq_kat(N, taps):
+    m = _MLS_base(N, tuple(taps))
+    s = m.get_full_sequence(repeats=1)
+    assert s.shape == (m.L, 1) and s.dtype == np.float64
+    packed = inputs.pack_bits_from_samples(s)
+    bits = ((1.0 - s[:, 0]) / 2.0).astype(np.uint8)
+    return {
+        "N": N, "taps": list(taps), "ones": int(bits.sum()),
+        "sha256": inputs.digest(packed),
+        "first64": "".join(str(int(b)) for b in bits[:64]),
+        "nbytes": int(packed.size),
+    }
+
+
+def dump_seq_kats(quick):
+    out = []
+    t0 = time.time()
+    for N in sorted(TAPS):
+        if N <= 12:
+            sets = list(TAPS[N])
+        elif N <= (20 if quick else 24):
+            sets = [TAPS[N][0], TAPS[N][-1]]
+            if N <= 16:
+                sets.append(TAPS[N][len(TAPS[N]) // 2])
+        else:
+            continue
+        for taps in sets:
+            out.append(seq_kat(N, taps))
+        print("seq KAT N=%d (%d sets) %.0fs" % (N, len(sets), time.time() - t0), flush=True)
+    # generator_chunk continuity across the period boundary
+    m = _MLS_base(5, TAPS[5][1])
+    g = m.generator_chunk(20)
+    chunks = [next(g) for _ in range(4)]
+    assert chunks[0].shape == (20, 1) and chunks[0].dtype == np.int64
+    cont = {"N": 5, "taps": list(TAPS[5][1]), "chunk": 20,
+            "bits": [int(v) for c in chunks for v in c[:, 0]]}
+    gs = m.generator_samples(7)
+    sam = [next(gs) for _ in range(3)]
+    cont["samples_chunk7"] = [float(v) for c in sam for v in c[:, 0]]
+    write_json("seq_kat.json", {"kats": out, "generator_chunk": cont})
+
+
+# --------------------------------------------------------------------------- IR goldens
+def ref_impulse(N, taps, x):
+    m = _MLS_base(N, tuple(taps))
+    avg = m.trim_and_avgerage(x)
+    h = m.get_impulse(x)
+    assert h.shape == (m.L, 1) and h.dtype == np.float64
+    return h[:, 0].copy(), str(avg.dtype)
+
+
+def dump_ir(quick):
+    arrays = {}
+    meta = []
+    small = []
+    for N in (3, 4, 5, 7, 8, 10, 11, 12):
+        small.append((N, TAPS[N][0], "loopback", 2, 1, "col", "float64"))
+        small.append((N, TAPS[N][-1], "noise", 4, 2, "flat", "float64"))
+        small.append((N, TAPS[N][len(TAPS[N]) // 2], "system", 5, 3, "col", "float64"))
+    small.append((10, TAPS[10][3], "system", 3, 4, "col", "float32"))
+    small.append((10, TAPS[10][4], "system", 3, 5, "flat", "int16"))
+    small.append((12, TAPS[12][7], "noise", 2, 6, "col", "float32"))
+    small.append((13, TAPS[13][0], "system", 17, 7, "col", "float64"))
+    small.append((14, TAPS[14][0], "system", 3, 8, "col", "float64"))
+    for cid, (N, taps, kind, R, seed, shape, dtype) in enumerate(small):
+        seq = _MLS_base(N, tuple(taps)).get_full_sequence(1)[:, 0]
+        x = inputs.make_input(kind, seq, R, seed, shape, dtype)
+        h, avg_dtype = ref_impulse(N, taps, x)
+        key = "c%02d" % cid
+        arrays[key + "_h"] = h
+        store_x = N <= 10
+        if store_x:
+            arrays[key + "_x"] = x
+        meta.append({"id": key, "N": N, "taps": list(taps), "kind": kind, "R": R, "seed": seed,
+                     "shape": shape, "dtype": dtype, "x_sha256": inputs.digest(x),
+                     "x_stored": store_x, "avg_dtype": avg_dtype,
+                     "peak": float(np.max(np.abs(h))), "argmax": int(np.argmax(np.abs(h)))})
+        print("IR small", key, N, kind, R, dtype, flush=True)
+    np.savez_compressed(os.path.join(HERE, "ir_small.npz"), **arrays)
+    write_json("ir_small.json", {"cases": meta})
+
+    large = [
+        (16, TAPS[16][0], "system", 2, 11, "col", "float64"),   # BASELINE config 1 shape
+        (16, TAPS[16][0], "system", 5, 12, "col", "float64"),   # ex_mls.py rep=5
+        (18, TAPS[18][0], "system", 2, 13, "col", "float64"),   # config 2 order
+        (18, TAPS[18][-1], "noise", 3, 14, "flat", "float32"),
+        (20, TAPS[20][0], "system", 2, 15, "col", "float64"),   # config 5 order
+        (20, TAPS[20][0], "system", 17, 16, "col", "float64"),  # config 3 shape
+    ]
+    if not quick:
+        large.append((24, TAPS[24][0], "system", 2, 17, "col", "float64"))  # config 4 order
+    arrays = {}
+    meta = []
+    for cid, (N, taps, kind, R, seed, shape, dtype) in enumerate(large):
+        t0 = time.time()
+        seq = _MLS_base(N, tuple(taps)).get_full_sequence(1)[:, 0]
+        x = inputs.make_input(kind, seq, R, seed, shape, dtype)
+        h, avg_dtype = ref_impulse(N, taps, x)
+        idx = inputs.sparse_indices(len(h), seed)
+        key = "L%02d" % cid
+        arrays[key + "_idx"] = idx.astype(np.int64)
+        arrays[key + "_h"] = h[idx]
+        # always keep the neighbourhood of the peak (the part a user looks at)
+        am = int(np.argmax(np.abs(h)))
+        lo = max(0, am - 64)
+        arrays[key + "_peakwin"] = h[lo:lo + 256]
+        meta.append({"id": key, "N": N, "taps": list(taps), "kind": kind, "R": R, "seed": seed,
+                     "shape": shape, "dtype": dtype, "x_sha256": inputs.digest(x),
+                     "avg_dtype": avg_dtype, "argmax": am, "peakwin_lo": lo,
+                     "max": float(h[am]), "peak": float(np.max(np.abs(h))),
+                     "sum": float(np.sum(h)), "sumsq": float(np.sum(h * h))})
+        print("IR large", key, N, kind, R, dtype, "%.1fs" % (time.time() - t0), flush=True)
+        del x, h, seq
+    np.savez_compressed(os.path.join(HERE, "ir_large.npz"), **arrays)
+    write_json("ir_large.json", {"cases": meta})
+
+
+# --------------------------------------------------------------------------- error table
+def exc_name(fn):
+    try:
+        fn()
+    except BaseException as e:  # noqa: BLE001
+        return type(e).__name__, str(e)
+    return None, None
+
+
+def dump_errors():
+    N, taps = 5, TAPS[5][0]
+    m = _MLS_base(N, taps)
+    L = m.L
+    good = m.get_full_sequence(3)
+    table = {
+        "ctor_N_none": exc_name(lambda: _MLS_base(None, taps)),
+        "ctor_taps_none": exc_name(lambda: _MLS_base(N, None)),
+        "ctor_taps_empty": exc_name(lambda: _MLS_base(N, ())),
+        "ctor_taps_ndarray": exc_name(lambda: _MLS_base(N, np.array(taps))),
+        "ctor_taps_list_ok": exc_name(lambda: _MLS_base(N, list(taps))),
+        "impulse_len_eq_L": exc_name(lambda: m.get_impulse(good[:L])),
+        "impulse_len_not_multiple": exc_name(lambda: m.get_impulse(np.zeros(2 * L + 3))),
+        "impulse_two_channels": exc_name(lambda: m.get_impulse(np.zeros((2 * L, 2)))),
+        "impulse_list": exc_name(lambda: m.get_impulse(list(good[:, 0]))),
+        "impulse_ok": exc_name(lambda: m.get_impulse(good)),
+        "mls_repeats_1": exc_name(lambda: MLS(N, taps, repeats=1)),
+        "mls_non_minphase": exc_name(lambda: MLS(N, taps, repeats=2, B=(1, 2, 0), A=(1, 0, 0))),
+        "random_taps_unknown_N": exc_name(lambda: get_random_taps(99)),
+        "taps_keyerror": exc_name(lambda: TAPS[99]),
+    }
+    write_json("errors.json", {k: {"type": v[0], "msg": v[1]} for k, v in table.items()})
+
+
+# --------------------------------------------------------------------------- class-level API goldens
+def dump_api():
+    arrays = {}
+    meta = {}
+    # MLS with an RBJ high-shelf emphasis, as in examples/ex_mls.py but small
+    fs, N, rep = 48000, 10, 3
+    f = zignal.filters.biquads.RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=fs)
+    B, A = f.get_coefficients()
+    mls = MLS(N=N, taps=TAPS[N][0], fs=fs, repeats=rep, B=B, A=A)
+    meta["mls"] = {"N": N, "fs": fs, "repeats": rep, "taps": list(TAPS[N][0]),
+                   "B": [float(b) for b in B], "A": [float(a) for a in A],
+                   "samples_shape": list(mls.samples.shape), "samples_dtype": str(mls.samples.dtype),
+                   "str": str(mls), "nofsamples": mls.nofsamples, "ch": mls.ch,
+                   "duration": mls.duration}
+    arrays["mls_raw"] = mls.samples.copy()
+    mls.apply_emphasis()
+    arrays["mls_emph"] = mls.samples.copy()
+    # a fake system: delay by 100 samples and scale, then de-emphasis, then IR
+    y = np.roll(mls.samples, 100, axis=0) * 0.5
+    z = mls.apply_deemphasis(y)
+    arrays["mls_deemph"] = z.copy()
+    k = mls.get_impulse(z)
+    assert isinstance(k, zignal.Audio)
+    meta["mls"]["ir_shape"] = list(k.samples.shape)
+    meta["mls"]["ir_fs"] = k.fs
+    meta["mls"]["ir_ch"] = k.ch
+    meta["mls"]["ir_nofsamples"] = k.nofsamples
+    arrays["mls_ir"] = k.samples.copy()
+
+    # MLS_simple loop-back, as in `python -m zignal.measure.mls` but N=10
+    ms = MLS_simple(N=10, fs=96000, repeats=4)
+    meta["simple"] = {"N": 10, "fs": 96000, "repeats": 4, "repr": repr(ms), "str": str(ms),
+                      "samples_shape": list(ms.samples.shape)}
+    arrays["simple_samples"] = ms.samples.copy()
+    ir = ms.get_impulse(ms.samples)
+    arrays["simple_ir"] = ir.samples.copy()
+
+    # all nine RBJ types (MLS users pick their own emphasis filter)
+    rbj = {}
+    for ft in ("lowpass", "highpass", "bandpass1", "bandpass2", "notch", "allpass", "peak",
+               "lowshelf", "highshelf"):
+        ff = zignal.filters.biquads.RBJ(filtertype=ft, gaindb=-6.5, f0=1234.0, Q=1.3, fs=44100)
+        b, a = ff.get_coefficients()
+        rbj[ft] = {"B": [float(v) for v in b], "A": [float(v) for v in a],
+                   "minphase": bool(ff.is_minimum_phase())}
+    meta["rbj"] = {"gaindb": -6.5, "f0": 1234.0, "Q": 1.3, "fs": 44100, "types": rbj}
+    np.savez_compressed(os.path.join(HERE, "api.npz"), **arrays)
+    write_json("api.json", meta)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    steps = {"taps": dump_taps, "errors": dump_errors, "api": dump_api,
+             "seq": lambda: dump_seq_kats(a.quick), "ir": lambda: dump_ir(a.quick)}
+    for name, fn in steps.items():
+        if a.only and name not in a.only.split(","):
+            continue
+        print("==", name, flush=True)
+        fn()
+    print("done")
