@@ -1,0 +1,145 @@
+/* zmls — MI355X (gfx950) implementation of zignal's MLS measurement hot path.
+ *
+ * C ABI of libzmls.so. The reference (zignal v0.6.0) is pure Python and has no
+ * FFI boundary of its own; each entry point below names the reference method
+ * whose work it takes over (file:line under the reference root). Plain pointers
+ * and sizes only; no exceptions cross the boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative zmls_status; the text of
+ *     the last error on the calling thread is zmls_last_error().
+ *   - "frames" are sample rows, "channels" are columns: element (j, c) of a
+ *     capture lives at  base + (j*row_stride + c*ch_stride) * sizeof(element).
+ *     (R*L, C) C-contiguous (zignal's Audio layout, audio.py:34) is
+ *     row_stride=C, ch_stride=1; a stack of single-channel captures (C, R*L) is
+ *     row_stride=1, ch_stride=R*L.
+ *   - a plan owns its device buffers (bit sequence, permutation tables,
+ *     workspace). Launch entry points (`*_device`) never allocate, free or
+ *     synchronise; they enqueue on the caller's HIP stream.
+ *   - one plan is not thread-safe; different plans are independent.
+ */
+#ifndef ZMLS_H
+#define ZMLS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ZMLS_OK = 0,
+    ZMLS_E_ARG = -1,        /* bad argument (Python shim raises AssertionError/ValueError as the reference does) */
+    ZMLS_E_HIP = -2,        /* a HIP runtime call failed */
+    ZMLS_E_NODEVICE = -3,   /* no usable GPU: there is NO CPU fallback */
+    ZMLS_E_WORKSPACE = -4,  /* plan workspace too small for even one channel slab */
+    ZMLS_E_UNSUPPORTED = -5
+} zmls_status;
+
+typedef enum { ZMLS_F64 = 0, ZMLS_F32 = 1, ZMLS_I16 = 2, ZMLS_I32 = 3 } zmls_dtype;
+
+typedef struct zmls_plan zmls_plan;
+
+const char *zmls_last_error(void);
+int zmls_version(void);
+int zmls_device_count(int *n);
+
+/* ---- plan: replaces _MLS_base.__init__ (zignal/measure/mls.py:64-76) plus the
+ * work the reference redoes on every call: the per-bit LFSR loop of
+ * generator_bit/generator_chunk (mls.py:91-128) and the regeneration of the
+ * stimulus inside xcorr_circular (mls.py:207).
+ * taps: 1-indexed feedback delays as in zignal/measure/mlstaps.py:16-17; max(taps) must be N.
+ * dtype: arithmetic type of the impulse-response path, ZMLS_F64 (reference) or ZMLS_F32.
+ * device: HIP device ordinal. 2 <= N <= 30. */
+int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int dtype, int device);
+int zmls_plan_destroy(zmls_plan *p);
+/* Make sure the workspace can hold `n_ch` channels in one go (allocates; call outside timed/captured regions). */
+int zmls_plan_reserve(zmls_plan *p, int64_t n_ch);
+/* info[0]=N info[1]=L info[2]=dtype info[3]=device info[4]=number of FWHT passes
+ * info[5..7]=bits per pass info[8]=workspace bytes info[9]=channels per slab */
+int zmls_plan_info(const zmls_plan *p, int64_t info[16]);
+
+/* ---- sequence: replaces generator_bit / generator_chunk / generator_samples /
+ * get_full_sequence (mls.py:91-167). */
+/* first `nbits` bits of the generator (it runs on across the period boundary,
+ * mls.py:117-128), LSB-first packed, unused bits of the last byte zero;
+ * nbits <= 2^N + 32. */
+int zmls_sequence_bits(zmls_plan *p, uint8_t *out_packed, int64_t nbits);
+/* repeats*L samples, bit 0 -> +1.0, bit 1 -> -1.0 (mls.py:150), host buffer */
+int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats);
+/* same on the device: d_out holds repeats*L elements of `dtype` (F64/F32), element stride `stride` */
+int zmls_sequence_device(zmls_plan *p, void *d_out, int dtype, int64_t repeats, int64_t stride, void *hip_stream);
+
+/* ---- impulse response: replaces trim_and_avgerage (mls.py:258-313) +
+ * xcorr_circular (mls.py:169-256) = _MLS_base.get_impulse (mls.py:315-328),
+ * for n_ch independent channels at once.
+ *   x      : n_rows = R*L frames (R >= 2), n_ch channels, element type in_dtype
+ *   h      : L frames, n_ch channels, element type = the plan's dtype
+ * Period 0 is discarded, periods 1..R-1 are averaged, the average is circularly
+ * cross-correlated with the plan's sequence and divided by L. */
+int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch,
+                        int64_t row_stride, int64_t ch_stride,
+                        void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
+/* host buffers: uploads, runs, downloads, synchronous. h element type = plan dtype. */
+int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch,
+                      int64_t row_stride, int64_t ch_stride,
+                      void *h, int64_t out_row_stride, int64_t out_ch_stride);
+
+/* ---- the averaging step alone: replaces trim_and_avgerage (mls.py:258-313) when it is called
+ * on its own. out: (L, n_ch) C-contiguous HOST buffer, float32 when in_dtype is ZMLS_F32 (numpy
+ * averages float32 in float32), float64 otherwise. */
+int zmls_average_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch,
+                      int64_t row_stride, int64_t ch_stride, void *out);
+
+/* ---- synthetic captures for benchmarking/tests (no reference counterpart; the
+ * shape follows examples/ex_mls.py:16-28: stimulus through a short filter with a
+ * delay, plus noise). Channel c: 16-tap decaying FIR g_c, delay d_c =
+ * (c*9973) mod L, sigma*noise per sample, `repeats` periods, steady state.
+ * Writes element type `dtype` with the given strides. */
+int zmls_synth_device(zmls_plan *p, void *d_x, int dtype, int64_t repeats, int64_t n_ch, int64_t ch_first,
+                      int64_t row_stride, int64_t ch_stride, uint64_t seed, double sigma, void *hip_stream);
+/* the FIR the synthetic channel c uses (16 doubles) and its delay */
+int zmls_synth_system(const zmls_plan *p, int64_t channel, uint64_t seed, double *taps16, int64_t *delay);
+
+/* ---- device memory and streams for ctypes callers that have no HIP binding of
+ * their own (bench.py, tests). Thin wrappers over hipMalloc, hipFree, hipMemcpy and the
+ * hipStream / hipEvent calls, on the given device. */
+int zmls_dev_alloc(int device, void **d_ptr, size_t bytes);
+int zmls_dev_free(int device, void *d_ptr);
+int zmls_dev_upload(int device, void *d_dst, const void *src, size_t bytes);
+int zmls_dev_download(int device, void *dst, const void *d_src, size_t bytes);
+int zmls_dev_memset(int device, void *d_ptr, int value, size_t bytes);
+int zmls_dev_sync(int device);
+int zmls_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
+int zmls_stream_create(int device, void **stream);
+int zmls_stream_destroy(int device, void *stream);
+int zmls_stream_sync(int device, void *stream);
+int zmls_event_create(int device, void **event);
+int zmls_event_destroy(int device, void *event);
+int zmls_event_record(int device, void *event, void *stream);
+int zmls_event_elapsed_ms(int device, void *start, void *stop, float *ms); /* synchronises on `stop` */
+/* strided 2-D gather of one channel into a contiguous device/host buffer (tests: pull column c of a big capture) */
+int zmls_dev_download_channel(int device, void *dst, const void *d_src, int dtype, int64_t n_rows,
+                              int64_t row_stride, int64_t ch_stride, int64_t channel);
+
+/* ---- plan internals for tests (tables in natural order, host buffers of 2^N uint32):
+ * which=0: gather table   Q[d] = j with Ps[j] = d   (Q[0] = 0xFFFFFFFF)
+ * which=1: scatter table  M[d] = m with Pl[m] = d   (M[0] = 0xFFFFFFFF)
+ * Ps / Pl as defined in SURVEY.md §A.2. */
+int zmls_plan_export_table(zmls_plan *p, int which, uint32_t *out);
+
+/* ---- host-only helpers (no GPU needed; used by the CPU test tier) */
+/* how a 2^N-point transform is split into LDS-resident passes: bits[i] for i < returned count */
+int zmls_host_pass_split(int N, int bits[4]);
+/* state of the N-bit Fibonacci register after `steps` steps from the reference's initial state, computed
+ * with the same GF(2) jump-ahead matrices the device kernels use; bit i = sequence bit (steps + i). */
+int zmls_host_lfsr_state(int N, const int32_t *taps, int ntaps, uint64_t steps, uint32_t *state);
+/* enumerate the tile geometry of one pass and verify every element is covered exactly once per round and
+ * every LDS slot / workspace row is in range; returns 0 if consistent. */
+int zmls_host_geometry_selfcheck(int K, int log2_units, int first_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZMLS_H */

@@ -1,0 +1,218 @@
+"""GPU parity, floating-point part: impulse responses from the HIP path (through the C ABI)
+against the golden fixtures captured from the reference and against the oracle.
+
+Tolerances (BASELINE.json north_star): fp64 max-abs error <= 1e-12 x peak; fp32 mode <= 1e-5 x
+peak. float32 CAPTURES are special: the reference transforms a float32 average with a
+single-precision FFT, so its own output is ~1e-7 x peak off the exact correlation; those cases
+are held to 1e-6 x peak."""
+import os
+
+import numpy as np
+import pytest
+
+import inputs
+from gpu_common import G, case_input, load_json, oracle_ir, plan, rel_err
+from oracle import c_oracle, mls_oracle
+from zignal_amd import _lib
+from zignal_amd.device import DeviceBuffer
+from zignal_amd.measure.mls import MLS, TAPS, MLS_simple, _MLS_base
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-12
+TOL32 = 1e-5
+IR_SMALL = load_json("ir_small.json")["cases"]
+IR_LARGE = load_json("ir_large.json")["cases"]
+
+
+def _tol(case):
+    return 1e-6 if case["dtype"] == "float32" else TOL64
+
+
+@pytest.mark.parametrize("case", IR_SMALL, ids=lambda c: "%s-N%d-%s-%s" % (c["id"], c["N"], c["kind"], c["dtype"]))
+def test_golden_ir_small(case):
+    arrays = np.load(os.path.join(G, "ir_small.npz"))
+    x = case_input(case)
+    m = _MLS_base(case["N"], tuple(case["taps"]), device=0)
+    h = m.get_impulse(x)
+    assert h.shape == (m.L, 1) and h.dtype == np.float64 and h.flags.c_contiguous
+    assert rel_err(h[:, 0], arrays[case["id"] + "_h"]) <= _tol(case)
+    avg = m.trim_and_avgerage(x)
+    assert avg.shape == (m.L, 1) and str(avg.dtype) == case["avg_dtype"]
+    assert rel_err(avg, mls_oracle.trim_and_average(x, m.L)) <= (1e-6 if case["dtype"] == "float32" else 1e-15)
+    if case["dtype"] == "float64":
+        assert rel_err(m.xcorr_circular(avg)[:, 0], arrays[case["id"] + "_h"]) <= TOL64
+    # optional fp32 arithmetic
+    h32 = _MLS_base(case["N"], tuple(case["taps"]), dtype="f32", device=0).get_impulse(x)
+    assert h32.dtype == np.float64 and rel_err(h32[:, 0], arrays[case["id"] + "_h"]) <= TOL32
+
+
+@pytest.mark.parametrize("case", IR_LARGE, ids=lambda c: "%s-N%d-%s-R%d" % (c["id"], c["N"], c["kind"], c["R"]))
+def test_golden_ir_large(case):
+    arrays = np.load(os.path.join(G, "ir_large.npz"))
+    x = case_input(case)
+    h = plan(case["N"], case["taps"]).impulse_host(x)[:, 0]
+    tol = _tol(case) * case["peak"]
+    k = case["id"]
+    assert np.max(np.abs(h[arrays[k + "_idx"]] - arrays[k + "_h"])) <= tol
+    lo = case["peakwin_lo"]
+    assert np.max(np.abs(h[lo:lo + 256] - arrays[k + "_peakwin"])) <= tol
+    assert int(np.argmax(np.abs(h))) == case["argmax"]
+    assert abs(float(h[case["argmax"]]) - case["max"]) <= tol
+    assert abs(float(np.sum(h)) - case["sum"]) <= 1e-9 * max(1.0, abs(case["sum"]))
+    assert abs(float(np.sum(h * h)) - case["sumsq"]) <= 1e-9 * case["sumsq"]
+    if case["N"] <= 20 and case["dtype"] == "float64":
+        h32 = plan(case["N"], case["taps"], "f32").impulse_host(x)[:, 0]
+        assert np.max(np.abs(h32[arrays[k + "_idx"]] - arrays[k + "_h"])) <= TOL32 * case["peak"]
+
+
+def test_reference_comment_example_on_device():
+    m = _MLS_base(3, (3, 2), device=0)
+    s = m.get_full_sequence(2)
+    assert s[:7, 0].tolist() == [1, -1, -1, -1, 1, 1, -1]          # mls.py:183
+    h = m.get_impulse(s)
+    assert np.allclose(h[:, 0], [1] + [-1 / 7] * 6, atol=1e-15)     # mls.py:205
+
+
+@pytest.mark.parametrize("N", list(range(3, 21)))
+def test_every_order_against_oracle(N):
+    """All pass splits (1 pass up to N=10, 2 passes above), first and last tap set, noise input."""
+    rng = np.random.default_rng(1000 + N)
+    for taps in (TAPS[N][0], TAPS[N][-1]):
+        L = (1 << N) - 1
+        R = 3 if N < 18 else 2
+        x = rng.standard_normal((R * L, 1))
+        want = oracle_ir(N, taps, x)
+        assert rel_err(plan(N, taps).impulse_host(x)[:, 0], want) <= TOL64
+        assert rel_err(plan(N, taps, "f32").impulse_host(x)[:, 0], want) <= TOL32
+
+
+@pytest.mark.parametrize("N,C", [(5, 1), (7, 3), (9, 8), (10, 37), (12, 1), (12, 5), (13, 16), (14, 24), (16, 10), (17, 33)])
+def test_multichannel_layouts(N, C):
+    """(R*L, C) frame-major (vector path when C is a multiple of the vector width, element path
+    otherwise), a transposed view (capture-major strides) and float32 captures: each column must
+    equal the single-channel oracle result."""
+    taps = TAPS[N][1 % len(TAPS[N])]
+    L = (1 << N) - 1
+    R = 4
+    rng = np.random.default_rng(N * 100 + C)
+    x = rng.standard_normal((R * L, C))
+    ref = c_oracle.sequence(N, taps)
+    want = np.stack([oracle_ir(N, taps, np.ascontiguousarray(x[:, c:c + 1]), ref) for c in range(C)], axis=1)
+    p = plan(N, taps)
+    h = p.impulse_host(x)
+    assert h.shape == (L, C) and h.dtype == np.float64
+    assert rel_err(h, want) <= TOL64
+    xt = np.ascontiguousarray(x.T).T            # same values, capture-major memory
+    assert xt.strides[0] == 8 and rel_err(p.impulse_host(xt), want) <= TOL64
+    xs = np.zeros((R * L, 2 * C + 3))
+    xs[:, 1:2 * C + 1:2] = x                    # every other column of a wider buffer
+    assert rel_err(p.impulse_host(xs[:, 1:2 * C + 1:2]), want) <= TOL64
+    x32 = x.astype(np.float32)
+    want32 = np.stack([oracle_ir(N, taps, np.ascontiguousarray(x32[:, c:c + 1]).astype(np.float64), ref)
+                       for c in range(C)], axis=1)
+    assert rel_err(p.impulse_host(x32), want32) <= 1e-6
+    p32 = plan(N, taps, "f32")
+    assert rel_err(p32.impulse_host(x32), want32) <= TOL32
+    m = _MLS_base(N, taps, device=0)
+    assert rel_err(m.get_impulses(x), want) <= TOL64
+
+
+def test_device_entry_point_chunks_channels_with_small_workspace():
+    """zmls_impulse_device never allocates: with a workspace of one slab it must loop over the
+    channel slabs itself and still give the same answer; with none it must refuse."""
+    N, C, R = 13, 24, 3
+    taps = TAPS[N][0]
+    L = (1 << N) - 1
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((R * L, C))
+    want = plan(N, taps).impulse_host(x)
+    from zignal_amd.device import Plan
+    p = Plan(N, taps, device=0)
+    dx = DeviceBuffer(x.nbytes).upload(x)
+    dh = DeviceBuffer(L * C * 8)
+    with pytest.raises(_lib.ZmlsError) as ei:
+        p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)
+    assert ei.value.code == _lib.E_WORKSPACE
+    p.reserve(8)                                  # one slab of 8 float64 channels
+    assert p.info()["workspace_bytes"] == (1 << N) * 64
+    p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)
+    got = dh.download((L, C), np.float64)
+    assert np.array_equal(got, want)              # same kernels, same order of operations
+    p.close()
+
+
+def test_linearity_shift_and_sum_properties():
+    N, taps = 15, TAPS[15][0]
+    L = (1 << N) - 1
+    rng = np.random.default_rng(3)
+    p = plan(N, taps)
+    a = rng.standard_normal((2 * L, 1))
+    b = rng.standard_normal((2 * L, 1))
+    ha, hb = p.impulse_host(a), p.impulse_host(b)
+    hab = p.impulse_host(2.5 * a - 0.75 * b)
+    assert rel_err(hab, 2.5 * ha - 0.75 * hb) <= 1e-13
+    d = 12345
+    a_shift = np.concatenate((np.roll(a[:L], d, axis=0), np.roll(a[L:], d, axis=0)))
+    assert rel_err(p.impulse_host(a_shift), np.roll(ha, d, axis=0)) <= 1e-13
+    # sum_m h[m] = -(1/L) sum_j avg[j]
+    assert abs(float(ha.sum()) + float(a[L:].sum()) / L) <= 1e-12 * max(1.0, abs(float(ha.sum())))
+    # loop-back: two-valued autocorrelation
+    s = p.sequence(3)
+    h = p.impulse_host(s)[:, 0]
+    assert h[0] == 1.0 and np.max(np.abs(h[1:] + 1.0 / L)) <= 1e-18 + 1e-16 / L
+    # a pure delay moves the peak
+    hd = p.impulse_host(np.roll(s, 777, axis=0))[:, 0]
+    assert int(np.argmax(hd)) == 777 and hd[777] == 1.0
+
+
+def test_integer_captures():
+    N, taps = 12, TAPS[12][3]
+    L = (1 << N) - 1
+    rng = np.random.default_rng(5)
+    p = plan(N, taps)
+    for dt in (np.int16, np.int32):
+        x = rng.integers(-20000, 20000, size=(3 * L, 2)).astype(dt)
+        want = np.stack([oracle_ir(N, taps, np.ascontiguousarray(x[:, c:c + 1])) for c in range(2)], axis=1)
+        assert rel_err(p.impulse_host(x), want) <= TOL64
+
+
+def test_error_behaviour_through_the_c_abi():
+    p = plan(5, (5, 3))
+    L = 31
+    lib = _lib.lib()
+    x = np.zeros((3 * L, 1))
+    h = np.zeros((L, 1))
+    a = lambda n_rows: lib.zmls_impulse_host(p._h, x.ctypes.data, 0, n_rows, 1, 1, 1, h.ctypes.data, 1, 1)  # noqa: E731
+    assert a(L) == _lib.E_ARG and "thrown away" in _lib.last_error()
+    assert a(2 * L + 3) == _lib.E_ARG and "multiple" in _lib.last_error()
+    assert a(3 * L) == 0
+    assert lib.zmls_impulse_host(p._h, x.ctypes.data, 9, 3 * L, 1, 1, 1, h.ctypes.data, 1, 1) == _lib.E_ARG
+    assert lib.zmls_impulse_host(p._h, None, 0, 3 * L, 1, 1, 1, h.ctypes.data, 1, 1) == _lib.E_ARG
+
+
+def test_mls_and_mls_simple_classes_against_reference_goldens():
+    meta = load_json("api.json")
+    arrays = np.load(os.path.join(G, "api.npz"))
+    g = meta["mls"]
+    mls = MLS(N=g["N"], taps=tuple(g["taps"]), fs=g["fs"], repeats=g["repeats"], B=g["B"], A=g["A"], device=0)
+    assert list(mls.samples.shape) == g["samples_shape"] and str(mls.samples.dtype) == g["samples_dtype"]
+    assert (mls.nofsamples, mls.ch, mls.duration) == (g["nofsamples"], g["ch"], g["duration"])
+    assert np.array_equal(mls.samples, arrays["mls_raw"])
+    assert str(mls) == g["str"]
+    mls.apply_emphasis()
+    assert np.array_equal(mls.samples, arrays["mls_emph"])
+    y = np.roll(mls.samples, 100, axis=0) * 0.5
+    z = mls.apply_deemphasis(y)
+    assert np.array_equal(z, arrays["mls_deemph"])
+    k = mls.get_impulse(z)
+    assert list(k.samples.shape) == g["ir_shape"] and (k.fs, k.ch, k.nofsamples) == (g["ir_fs"], g["ir_ch"], g["ir_nofsamples"])
+    assert rel_err(k.samples, arrays["mls_ir"]) <= TOL64
+    s = meta["simple"]
+    ms = MLS_simple(N=s["N"], fs=s["fs"], repeats=s["repeats"], device=0)
+    assert repr(ms) == s["repr"] and str(ms) == s["str"]
+    assert np.array_equal(ms.samples, arrays["simple_samples"])
+    ir = ms.get_impulse(ms.samples)
+    assert rel_err(ir.samples, arrays["simple_ir"]) <= TOL64
+    with pytest.raises(AssertionError):
+        MLS(5, (5, 3), repeats=2, B=(1, 2, 0), A=(1, 0, 0), device=0)      # not minimum phase

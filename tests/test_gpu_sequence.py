@@ -1,0 +1,98 @@
+"""GPU parity, integer part: the LFSR kernel's bit sequence must equal the reference's bit for
+bit (golden SHA-256 digests captured from the reference + the C oracle), and the permutation
+tables it builds must be the bijections SURVEY.md §A.2 defines."""
+import numpy as np
+import pytest
+
+import inputs
+from gpu_common import load_json, plan
+from oracle import c_oracle
+from zignal_amd.measure.mls import TAPS, _MLS_base
+
+pytestmark = pytest.mark.gpu
+
+KATS = load_json("seq_kat.json")
+
+
+def _kat_id(k):
+    return "N%d-%s" % (k["N"], "_".join(map(str, k["taps"])))
+
+
+# every tap set for N <= 8, then first/last(/middle) per order up to 24
+SEL = [k for k in KATS["kats"] if k["N"] <= 8 or k["N"] >= 13] + \
+      [k for i, k in enumerate(KATS["kats"]) if 9 <= k["N"] <= 12 and i % 7 == 0]
+
+
+@pytest.mark.parametrize("kat", SEL, ids=_kat_id)
+def test_sequence_bits_match_reference_digest(kat):
+    p = plan(kat["N"], kat["taps"])
+    packed = p.bits_packed()
+    assert packed.size == kat["nbytes"]
+    assert inputs.digest(packed) == kat["sha256"]
+    bits = np.unpackbits(packed, bitorder="little")[:p.L]
+    assert int(bits.sum()) == kat["ones"]
+    assert "".join(map(str, bits[:64])) == kat["first64"]
+
+
+@pytest.mark.parametrize("N", [25, 26])
+def test_sequence_beyond_reference_reach_matches_c_oracle(N):
+    # the reference's Python loop would need minutes here; the C oracle runs the same recurrence
+    taps = TAPS[N][0]
+    assert np.array_equal(plan(N, taps).bits_packed(), c_oracle.bits_packed(N, taps))
+
+
+def test_sequence_samples_and_generators():
+    g = KATS["generator_chunk"]
+    m = _MLS_base(g["N"], tuple(g["taps"]), device=0)
+    gen = m.generator_chunk(g["chunk"])
+    blocks = [next(gen) for _ in range(4)]
+    assert blocks[0].shape == (g["chunk"], 1) and blocks[0].dtype == np.int64
+    assert [int(v) for b in blocks for v in b[:, 0]] == g["bits"]
+    gs = m.generator_samples(7)
+    sam = [next(gs) for _ in range(3)]
+    assert sam[0].dtype == np.float64 and sam[0].shape == (7, 1)
+    assert [float(v) for b in sam for v in b[:, 0]] == g["samples_chunk7"]
+    gb = m.generator_bit()
+    assert [next(gb) for _ in range(80)] == g["bits"]
+    s = m.get_full_sequence(3)
+    assert s.shape == (3 * m.L, 1) and s.dtype == np.float64 and s.flags.c_contiguous
+    assert np.array_equal(s, c_oracle.sequence(g["N"], g["taps"], 3))
+    # running past the period boundary through the C ABI (mls.py:117-128)
+    p = plan(g["N"], g["taps"])
+    nb = p.L + 32
+    assert np.array_equal(p.bits_packed(nb), c_oracle.bits_packed(g["N"], g["taps"], nb))
+
+
+@pytest.mark.parametrize("N,taps", [(3, (3, 2)), (8, (8, 7, 6, 1)), (11, TAPS[11][5]), (16, TAPS[16][0]),
+                                     (20, TAPS[20][0]), (22, TAPS[22][-1])])
+def test_permutation_tables(N, taps):
+    p = plan(N, taps)
+    L = p.L
+    q, m = p.tables()
+    assert q[0] == 0xFFFFFFFF and m[0] == 0xFFFFFFFF
+    # bijections onto 0..L-1
+    assert np.array_equal(np.sort(q[1:]), np.arange(L, dtype=np.uint32))
+    assert np.array_equal(np.sort(m[1:]), np.arange(L, dtype=np.uint32))
+    bits = np.unpackbits(c_oracle.bits_packed(N, taps, L + N), bitorder="little").astype(np.uint32)
+    # Ps[j] = N-bit window of the sequence starting at j  ->  Q[Ps[j]] = j
+    rng = np.random.default_rng(N)
+    js = np.concatenate(([0, 1, L - 1], rng.integers(0, L, 2000)))
+    for j in js:
+        w = int(sum(int(bits[j + i]) << i for i in range(N)))
+        assert q[w] == j
+    # Hadamard identity: a[(j - mm) mod L] = parity(Ps[j] & Pl[mm]), checked on random pairs
+    ps = np.empty(L, dtype=np.uint32)
+    ps[q[1:]] = np.arange(1, L + 1, dtype=np.uint32)
+    pl = np.empty(L, dtype=np.uint32)
+    pl[m[1:]] = np.arange(1, L + 1, dtype=np.uint32)
+    jj = rng.integers(0, L, 20000)
+    mm = rng.integers(0, L, 20000)
+    par = np.bitwise_count(ps[jj] & pl[mm]) & 1
+    assert np.array_equal(par.astype(np.uint32), bits[(jj - mm) % L])
+
+
+def test_non_maximal_taps_are_rejected_loudly():
+    from zignal_amd import _lib
+    with pytest.raises(_lib.ZmlsError) as ei:
+        plan(8, (8, 4))          # x^8 + x^4 + 1 is not primitive
+    assert ei.value.code == _lib.E_UNSUPPORTED and "maximum-length" in str(ei.value)

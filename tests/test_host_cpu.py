@@ -1,0 +1,162 @@
+"""CPU tier: the C-ABI library loads and exports everything include/zmls.h declares, the
+host-side logic (pass planner, GF(2) jump-ahead, tile geometry, argument checks, error
+types) behaves, and the product package never touches the oracle. No GPU compute here."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+from oracle import c_oracle  # noqa: E402
+from zignal_amd import _lib  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "zignal_amd", "csrc"), "-j8"])
+    return _lib.lib()
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "zmls.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(zmls_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libzmls.so does not export %s" % n
+    # and the ctypes table covers them all (plus zmls_last_error, bound separately)
+    assert set(names) - {"zmls_last_error"} == set(_lib.SIGNATURES)
+    assert lib.zmls_version() >= 100
+
+
+def test_pass_split(lib):
+    for N in range(2, 31):
+        bits = (ctypes.c_int * 4)()
+        n = lib.zmls_host_pass_split(N, bits)
+        b = list(bits)[:n]
+        assert sum(b) == N and max(b) <= 10 and n == -(-N // 10)
+        assert max(b) - min(b) <= 1 and b == sorted(b, reverse=True)
+    assert lib.zmls_host_pass_split(31, (ctypes.c_int * 4)()) == _lib.E_ARG
+
+
+@pytest.mark.parametrize("first", [0, 1])
+@pytest.mark.parametrize("K", range(1, 11))
+def test_tile_geometry_is_a_tiling(lib, K, first):
+    assert lib.zmls_host_geometry_selfcheck(K, 2, first) == 0, _lib.last_error()
+
+
+def _window(N, taps, steps):
+    bits = c_oracle.bits(N, taps, steps + N)
+    return int(sum(int(b) << i for i, b in enumerate(bits[steps:steps + N])))
+
+
+@pytest.mark.parametrize("N,taps", [(3, (3, 2)), (5, (5, 4, 3, 2)), (10, (10, 7)), (16, (16, 15, 13, 4)),
+                                     (20, (20, 17)), (24, (24, 23, 22, 17)), (30, (30, 29, 28, 7))])
+def test_jump_ahead_matches_bit_serial_oracle(lib, N, taps):
+    arr, n = _lib.taps_array(taps)
+    rng = np.random.default_rng(N)
+    steps = [0, 1, 2, N - 1, N, 1023, 1024, 4097] + [int(v) for v in rng.integers(0, 200000, 6)]
+    for s in steps:
+        out = ctypes.c_uint32()
+        assert lib.zmls_host_lfsr_state(N, arr, n, s, ctypes.byref(out)) == 0
+        assert out.value == _window(N, taps, s), (N, s)
+
+
+def test_bad_plan_arguments_without_gpu(lib):
+    h = ctypes.c_void_p()
+    arr, n = _lib.taps_array((5, 3))
+    # order out of range / tap out of range / register length not among the taps / bad dtype
+    assert lib.zmls_plan_create(ctypes.byref(h), 1, arr, n, 0, 0) == _lib.E_ARG
+    assert lib.zmls_plan_create(ctypes.byref(h), 31, arr, n, 0, 0) == _lib.E_ARG
+    assert lib.zmls_plan_create(ctypes.byref(h), 4, arr, n, 0, 0) == _lib.E_ARG
+    arr2, n2 = _lib.taps_array((4, 3))
+    assert lib.zmls_plan_create(ctypes.byref(h), 5, arr2, n2, 0, 0) == _lib.E_ARG
+    assert lib.zmls_plan_create(ctypes.byref(h), 5, arr, n, 7, 0) == _lib.E_ARG
+    assert "dtype" in _lib.last_error()
+
+
+def test_taps_table_digest():
+    from zignal_amd.measure.mlstaps import TAPS
+    want = open(os.path.join(G, "taps.json")).read()
+    got = json.dumps({str(N): [list(t) for t in TAPS[N]] for N in sorted(TAPS)}, separators=(",", ":"), sort_keys=True)
+    assert hashlib.sha256(got.encode()).hexdigest() == hashlib.sha256(want.strip().encode()).hexdigest()
+    assert sum(len(v) for v in TAPS.values()) == 1014 and sorted(TAPS) == list(range(3, 33))
+    assert all(t[0] == N for N, sets in TAPS.items() for t in sets)
+
+
+def test_api_argument_errors_match_reference_table():
+    """Exception types of the reference for malformed arguments (tests/golden/errors.json) —
+    all raised before any device work, so they can be checked without a GPU."""
+    from zignal_amd.measure.mls import MLS, TAPS, _MLS_base, get_random_taps
+    table = json.load(open(os.path.join(G, "errors.json")))
+
+    def name(fn):
+        try:
+            fn()
+        except BaseException as e:  # noqa: BLE001
+            return type(e).__name__, str(e)
+        return None, None
+
+    N, taps, L = 5, (5, 3), 31
+    m = _MLS_base(N, taps)
+    assert (m.N, m.L, m.taps) == (5, 31, (5, 3))
+    checks = {
+        "ctor_N_none": lambda: _MLS_base(None, taps),
+        "ctor_taps_none": lambda: _MLS_base(N, None),
+        "ctor_taps_empty": lambda: _MLS_base(N, ()),
+        "ctor_taps_ndarray": lambda: _MLS_base(N, np.array(taps)),
+        "ctor_taps_list_ok": lambda: _MLS_base(N, list(taps)),
+        "impulse_len_eq_L": lambda: m.get_impulse(np.zeros((L, 1))),
+        "impulse_len_not_multiple": lambda: m.get_impulse(np.zeros(2 * L + 3)),
+        "impulse_two_channels": lambda: m.get_impulse(np.zeros((2 * L, 2))),
+        "impulse_list": lambda: m.get_impulse([0.0] * (3 * L)),
+        "mls_repeats_1": lambda: MLS(N, taps, repeats=1),
+        "random_taps_unknown_N": lambda: get_random_taps(99),
+        "taps_keyerror": lambda: TAPS[99],
+    }
+    for key, fn in checks.items():
+        t, msg = name(fn)
+        assert t == table[key]["type"], key
+        if table[key]["msg"]:
+            assert msg.strip("'") == table[key]["msg"].strip("'"), key
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    n = ctypes.c_int()
+    lib.zmls_device_count(ctypes.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    from zignal_amd.measure.mls import _MLS_base
+    m = _MLS_base(5, (5, 3))
+    with pytest.raises(_lib.ZmlsError) as ei:
+        m.get_full_sequence(1)
+    assert ei.value.code == _lib.E_NODEVICE and "no CPU fallback" in str(ei.value)
+    with pytest.raises(_lib.ZmlsError):
+        m.get_impulse(np.zeros((62, 1)))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "zignal_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".inc")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "mls_oracle" not in txt and "/root/reference" not in txt, f
+    # importing the package must not drag in torch or the oracle
+    code = "import sys; import zignal_amd.measure.mls; print('torch' in sys.modules, any(m.startswith('oracle') for m in sys.modules))"
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode().split()
+    assert out == ["False", "False"]

@@ -1,0 +1,117 @@
+"""Minimal stand-in for zignal's `Audio` container — only what the MLS path touches.
+
+The hot path stores its stimulus in `Audio.samples` and hands the impulse response back as an
+`Audio` (zignal/measure/mls.py:361, 413). This shim reproduces the constructor contract of
+zignal/audio.py:25-104 for the `initialdata` case (copy, 1-D -> column, shape checks, fs /
+nofsamples / ch / duration bookkeeping) and the few read-only helpers `__str__` needs
+(audio.py:106-125, 463-531). Everything else in zignal's Audio (wav I/O, resampling, fades,
+plotting, ...) is outside the scope of this library.
+"""
+import logging
+
+import numpy as np
+
+
+class Audio(object):
+    def __init__(self, channels=0, fs=96000, nofsamples=0, duration=None, initialdata=None, dtype=np.float64):
+        self._logger = logging.getLogger(__name__)
+        assert fs > 0, "sample rate cannot be zero or negative"
+        self.fs = fs
+        self._comment = ''
+        if initialdata is None:
+            assert isinstance(channels, int)
+            assert not (nofsamples != 0 and duration is not None), "choose either samples or duration"
+            self.ch = channels
+            if duration is not None:
+                self.nofsamples, self.duration = int(duration * fs), duration
+            else:
+                self.nofsamples, self.duration = nofsamples, nofsamples / fs
+            self.samples = np.zeros((self.nofsamples, self.ch), dtype=dtype)
+            return
+        assert isinstance(initialdata, np.ndarray), 'Only numpy arrays are allowed as initial data'
+        assert channels == 0, "parameter 'channels' is redundant if initial data is specified"
+        assert nofsamples == 0, "parameter 'nofsamples' is redundant if initial data is specified"
+        assert duration is None, "parameter 'duration' is redundant if initial data is specified"
+        data = initialdata.copy()                     # callers keep ownership of what they passed in
+        if data.ndim == 1:
+            data = data[:, np.newaxis]
+        assert data.ndim == 2, 'shape must be (Nsamples, Nchannels)'
+        self.samples = data
+        self.nofsamples, self.ch = data.shape
+        assert self.nofsamples > self.ch, 'shape must be (Nsamples, Nchannels)'
+        self.duration = self.nofsamples / self.fs
+
+    def __len__(self):
+        return self.nofsamples
+
+    def copy(self):
+        return Audio(fs=self.fs, initialdata=self.samples)
+
+    # -- per-channel statistics shown by __str__ -------------------------------------------------
+    def _wide(self):
+        s = self.samples
+        return s if np.issubdtype(s.dtype, np.floating) else s.astype(np.int64)
+
+    def peak(self):
+        """(signed peak value, its row index) per channel"""
+        if len(self.samples) == 0:
+            return np.full(self.ch, np.nan), np.zeros(self.ch, dtype=np.int64)
+        idx = np.abs(self._wide()).argmax(axis=0)
+        return np.array([self.samples[r, c] for c, r in enumerate(idx)]), idx
+
+    def rms(self):
+        if len(self.samples) == 0:
+            return np.full(self.ch, np.nan)
+        if (self.samples == 0).all():
+            return np.zeros(self.ch)
+        return np.sqrt(np.mean(np.power(self._wide(), 2), axis=0))
+
+    def crest_factor(self):
+        if len(self.samples) == 0:
+            return np.full(self.ch, np.nan)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return np.abs(self.samples).max(axis=0) / self.rms()
+
+    def delay(self, n, channel=1):
+        """Delay one channel (1-indexed) by n samples, zeros shifted in (audio.py:328-331)."""
+        col = self.samples[:, channel - 1]
+        self.samples[:, channel - 1] = np.concatenate((np.zeros(n, dtype=col.dtype), col))[:len(col)]
+
+    def __str__(self):
+        rows = [
+            '=======================================',
+            'classname        : %s' % self.__class__.__name__,
+            'sample rate      : %.1f [Hz]' % self.fs,
+            'channels         : %i' % self.ch,
+            'duration         : %.3f [s]' % self.duration,
+            'datatype         : %s' % self.samples.dtype,
+            'samples per ch   : %i' % self.nofsamples,
+            'data size        : %.3f [Mb]' % (self.samples.nbytes / (1024 * 1024)),
+            'has comment      : %s' % ('yes' if len(self._comment) != 0 else 'no'),
+        ]
+        if self.ch != 0:
+            fmt = dict(precision=4, suppress_small=True)
+            rows.append('peak             : %s' % np.array_str(self.peak()[0], **fmt))
+            rows.append('RMS              : %s' % np.array_str(self.rms(), **fmt))
+            rows.append('crestfactor      : %s' % np.array_str(self.crest_factor(), **fmt))
+        rows.append('-----------------:---------------------')
+        return "\n".join(rows) + "\n"
+
+    def plot_fft(self, plotname=None, window='hamming', normalise=True, **kwargs):
+        """Magnitude response plot (audio.py:649-676). Plotting is outside this library's scope:
+        only the rectangular, un-normalised case MLS uses is offered, through matplotlib if present."""
+        if window != 'rectangular' or normalise:
+            raise NotImplementedError("zignal_amd.Audio.plot_fft only does window='rectangular', normalise=False")
+        import matplotlib.pyplot as plt
+        mag = 20 * np.log10(np.abs(np.fft.rfft(self.samples, axis=0)) + 1e-300)
+        freq = np.fft.rfftfreq(self.nofsamples, 1.0 / self.fs)
+        plt.figure()
+        plt.semilogx(freq[1:], mag[1:])
+        plt.xlabel('Frequency [Hz]')
+        plt.ylabel('Magnitude [dB]')
+        plt.grid(True)
+        if plotname is None:
+            plt.show()
+        else:
+            plt.savefig(plotname)
+            plt.close()

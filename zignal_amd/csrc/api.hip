@@ -1,0 +1,494 @@
+// C ABI of libzmls.so (declarations and the reference methods they replace: include/zmls.h).
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "zmls_internal.h"
+
+namespace zmls {
+int validate_taps(int N, const int32_t *taps, int ntaps, uint32_t *G, uint32_t *s0);
+namespace {
+
+size_t dtype_size(int dt)
+{
+    switch (dt) {
+    case ZMLS_F64: return 8;
+    case ZMLS_F32: return 4;
+    case ZMLS_I16: return 2;
+    case ZMLS_I32: return 4;
+    default: return 0;
+    }
+}
+
+int use_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); libzmls has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return ZMLS_E_NODEVICE;
+    }
+    if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return ZMLS_E_NODEVICE; }
+    ZHIP(hipSetDevice(device));
+    return ZMLS_OK;
+}
+
+__global__ void count_sentinels_kernel(const uint32_t *t, uint64_t n, unsigned long long *count)
+{
+    unsigned long long local = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        local += (t[i] == kSentinel);
+    if (local) atomicAdd(count, local);
+}
+
+size_t slab_bytes(const zmls_plan *p) { return ((size_t)1 << p->N) * (kVecBytes << kLU); }
+int chans_per_slab(const zmls_plan *p) { return (int)((kVecBytes << kLU) / dtype_size(p->dtype)); }
+
+void free_plan_buffers(zmls_plan *p)
+{
+    if (p->d_bits) (void)hipFree(p->d_bits);
+    if (p->d_gather) (void)hipFree(p->d_gather);
+    if (p->d_scatter_nat) (void)hipFree(p->d_scatter_nat);
+    if (p->d_scatter_perm) (void)hipFree(p->d_scatter_perm);
+    if (p->d_jt) (void)hipFree(p->d_jt);
+    if (p->d_work) (void)hipFree(p->d_work);
+}
+
+int build_plan(zmls_plan *p)
+{
+    const uint64_t n = 1ull << p->N;
+    JumpTables jt;
+    build_jump_tables(p->N, p->G, &jt);
+    ZHIP(hipMalloc((void **)&p->d_jt, sizeof jt));
+    ZHIP(hipMemcpy(p->d_jt, &jt, sizeof jt, hipMemcpyHostToDevice));
+    // bits: one period plus a margin so N-bit windows and generator_chunk() can run past the
+    // period boundary; rounded up to whole threads of the generator
+    p->n_words = ((n + 64 + 1023) / 1024) * 32;
+    ZHIP(hipMalloc((void **)&p->d_bits, p->n_words * 4));
+    ZHIP(hipMalloc((void **)&p->d_gather, n * 4));
+    ZHIP(hipMalloc((void **)&p->d_scatter_nat, n * 4));
+    ZHIP(hipMemsetAsync(p->d_gather, 0xFF, n * 4, 0));
+    ZHIP(hipMemsetAsync(p->d_scatter_nat, 0xFF, n * 4, 0));
+    int rc = launch_lfsr_tables(p->N, p->G, p->s0, p->d_jt, p->d_bits, p->n_words, p->d_gather, p->d_scatter_nat, 0);
+    if (rc) return rc;
+    // every window value 1..L must have been visited exactly once, else the taps do not give a
+    // maximum-length sequence and the Hadamard identity does not hold
+    unsigned long long *d_cnt = nullptr, h_cnt[2] = {0, 0};
+    ZHIP(hipMalloc((void **)&d_cnt, 16));
+    ZHIP(hipMemsetAsync(d_cnt, 0, 16, 0));
+    hipLaunchKernelGGL(count_sentinels_kernel, dim3(1024), dim3(256), 0, 0, p->d_gather, n, d_cnt);
+    hipLaunchKernelGGL(count_sentinels_kernel, dim3(1024), dim3(256), 0, 0, p->d_scatter_nat, n, d_cnt + 1);
+    ZHIP(hipGetLastError());
+    ZHIP(hipMemcpy(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost));
+    (void)hipFree(d_cnt);
+    if (h_cnt[0] || h_cnt[1]) {
+        set_error("taps do not generate a maximum-length sequence of order %d (%llu of %llu register states never occur)",
+                  p->N, h_cnt[0], (unsigned long long)p->L);
+        return ZMLS_E_UNSUPPORTED;
+    }
+    p->npass = pass_split(p->N, p->bits);
+    if (p->npass > 1) {
+        int b = 0;
+        for (int i = 0; i + 1 < p->npass; ++i) b += p->bits[i];
+        ZHIP(hipMalloc((void **)&p->d_scatter_perm, n * 4));
+        rc = launch_scatter_perm(p->N, p->bits[p->npass - 1], kLU, b, p->d_scatter_nat, p->d_scatter_perm, 0);
+        if (rc) return rc;
+    }
+    ZHIP(hipDeviceSynchronize());
+    return ZMLS_OK;
+}
+
+} // namespace
+} // namespace zmls
+
+using namespace zmls;
+
+extern "C" {
+
+int zmls_device_count(int *n)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *n = (e == hipSuccess) ? c : 0;
+    return ZMLS_OK;
+}
+
+int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int dtype, int device)
+{
+    if (!out) { set_error("null plan pointer"); return ZMLS_E_ARG; }
+    *out = nullptr;
+    if (dtype != ZMLS_F64 && dtype != ZMLS_F32) { set_error("plan dtype must be ZMLS_F64 or ZMLS_F32"); return ZMLS_E_ARG; }
+    uint32_t G, s0;
+    int rc = validate_taps(N, taps, ntaps, &G, &s0);
+    if (rc) return rc;
+    rc = use_device(device);
+    if (rc) return rc;
+    zmls_plan *p = (zmls_plan *)calloc(1, sizeof(zmls_plan));
+    if (!p) { set_error("out of host memory"); return ZMLS_E_ARG; }
+    p->N = N;
+    p->L = ((int64_t)1 << N) - 1;
+    p->ntaps = ntaps;
+    memcpy(p->taps, taps, sizeof(int32_t) * ntaps);
+    p->G = G;
+    p->s0 = s0;
+    p->dtype = dtype;
+    p->device = device;
+    rc = build_plan(p);
+    if (rc) { free_plan_buffers(p); free(p); return rc; }
+    *out = p;
+    return ZMLS_OK;
+}
+
+int zmls_plan_destroy(zmls_plan *p)
+{
+    if (!p) return ZMLS_OK;
+    if (hipSetDevice(p->device) == hipSuccess) free_plan_buffers(p);
+    free(p);
+    return ZMLS_OK;
+}
+
+int zmls_plan_reserve(zmls_plan *p, int64_t n_ch)
+{
+    if (!p || n_ch < 1) { set_error("bad reserve arguments"); return ZMLS_E_ARG; }
+    if (p->npass == 1) return ZMLS_OK;   // single-pass plans keep everything in LDS
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    const int cs = chans_per_slab(p);
+    const size_t need = (size_t)((n_ch + cs - 1) / cs) * slab_bytes(p);
+    if (need <= p->work_bytes) return ZMLS_OK;
+    if (p->d_work) { ZHIP(hipFree(p->d_work)); p->d_work = nullptr; p->work_bytes = 0; }
+    ZHIP(hipMalloc(&p->d_work, need));
+    p->work_bytes = need;
+    return ZMLS_OK;
+}
+
+int zmls_plan_info(const zmls_plan *p, int64_t info[16])
+{
+    if (!p) { set_error("null plan"); return ZMLS_E_ARG; }
+    memset(info, 0, sizeof(int64_t) * 16);
+    info[0] = p->N; info[1] = p->L; info[2] = p->dtype; info[3] = p->device; info[4] = p->npass;
+    info[5] = p->bits[0]; info[6] = p->bits[1]; info[7] = p->bits[2];
+    info[8] = (int64_t)p->work_bytes; info[9] = chans_per_slab(p);
+    return ZMLS_OK;
+}
+
+int zmls_sequence_bits(zmls_plan *p, uint8_t *out, int64_t nbits)
+{
+    if (!p || !out || nbits < 0 || (uint64_t)nbits > (1ull << p->N) + 32) { set_error("bad sequence_bits arguments"); return ZMLS_E_ARG; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    const size_t nbytes = (size_t)((nbits + 7) / 8);
+    if (!nbytes) return ZMLS_OK;
+    ZHIP(hipMemcpy(out, p->d_bits, nbytes, hipMemcpyDeviceToHost));
+    if (nbits & 7) out[nbytes - 1] &= (uint8_t)((1u << (nbits & 7)) - 1u);
+    return ZMLS_OK;
+}
+
+int zmls_sequence_device(zmls_plan *p, void *d_out, int dtype, int64_t repeats, int64_t stride, void *stream)
+{
+    if (!p || !d_out || repeats < 1 || stride < 1) { set_error("bad sequence_device arguments"); return ZMLS_E_ARG; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    return launch_sequence_expand(p->d_bits, p->L, d_out, dtype, repeats, stride, (hipStream_t)stream);
+}
+
+int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
+{
+    if (!p || !out || repeats < 1) { set_error("bad sequence_f64 arguments"); return ZMLS_E_ARG; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    double *d = nullptr;
+    ZHIP(hipMalloc((void **)&d, (size_t)p->L * 8));
+    rc = launch_sequence_expand(p->d_bits, p->L, d, ZMLS_F64, 1, 1, 0);
+    if (!rc) {
+        hipError_t e = hipMemcpy(out, d, (size_t)p->L * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(sequence)");
+    }
+    (void)hipFree(d);
+    if (rc) return rc;
+    for (int64_t r = 1; r < repeats; ++r) memcpy(out + r * p->L, out, (size_t)p->L * 8);   // np.tile, mls.py:164
+    return ZMLS_OK;
+}
+
+int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
+                        int64_t ch_stride, void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *stream)
+{
+    if (!p || !d_x || !d_h) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
+    if (n_ch < 1) { set_error("need at least one channel"); return ZMLS_E_ARG; }
+    if (n_rows <= p->L) { set_error("The first sequence will be thrown away: need more than L=%lld frames", (long long)p->L); return ZMLS_E_ARG; }
+    if (n_rows % p->L) { set_error("frame count %lld is not a multiple of L=%lld", (long long)n_rows, (long long)p->L); return ZMLS_E_ARG; }
+    if (row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("strides must be positive"); return ZMLS_E_ARG; }
+    const int64_t periods = n_rows / p->L - 1;
+    if (periods > 0x7FFFFFFF) { set_error("too many periods"); return ZMLS_E_ARG; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+
+    const size_t ts = dtype_size(p->dtype);
+    const int E = (int)(kVecBytes / ts);
+    const int CS = chans_per_slab(p);
+    const int64_t n_slabs = (n_ch + CS - 1) / CS;
+    const bool single = p->npass == 1;
+    const bool vec_in = !single && in_dtype == p->dtype && ch_stride == 1 && (row_stride * (int64_t)ts) % kVecBytes == 0 &&
+                        ((uintptr_t)d_x % kVecBytes) == 0 && n_ch % E == 0;
+    const bool vec_out = !single && out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 &&
+                         ((uintptr_t)d_h % kVecBytes) == 0 && n_ch % E == 0;
+    auto launch = (p->dtype == ZMLS_F64) ? launch_pass_f64 : launch_pass_f32;
+
+    PassArgs a;
+    memset(&a, 0, sizeof a);
+    a.N = p->N;
+    a.x = d_x; a.in_dtype = in_dtype; a.periods = (int)periods; a.L = p->L;
+    a.row_stride = row_stride; a.ch_stride = ch_stride; a.n_ch = n_ch;
+    a.gather = p->d_gather;
+    a.h = d_h; a.out_row_stride = out_row_stride; a.out_ch_stride = out_ch_stride;
+
+    if (single) {
+        const int K = p->bits[0];
+        const int LT = log2_tiles(K, kLU);
+        a.single = 1; a.b = 0; a.n_macro = 1;
+        a.n_slab_groups = (uint32_t)((n_slabs + (1 << LT) - 1) >> LT);
+        a.ch_first = 0;
+        a.scatter = p->d_scatter_nat;
+        return launch(K, IN_GATHER_ELEM, OUT_SCATTER_ELEM, a, st);
+    }
+
+    const int64_t cap = (int64_t)(p->work_bytes / slab_bytes(p));
+    if (cap < 1) {
+        set_error("plan workspace (%zu bytes) holds no channel slab (%zu bytes each): call zmls_plan_reserve first", p->work_bytes, slab_bytes(p));
+        return ZMLS_E_WORKSPACE;
+    }
+    a.work = p->d_work;
+    a.scatter = p->d_scatter_perm;
+    for (int64_t s0 = 0; s0 < n_slabs; s0 += cap) {
+        const uint32_t ns = (uint32_t)((n_slabs - s0 < cap) ? n_slabs - s0 : cap);
+        a.ch_first = s0 * CS;
+        a.n_slab_groups = ns;
+        int b = 0;
+        for (int i = 0; i < p->npass; ++i) {
+            const int K = p->bits[i];
+            const int LT = log2_tiles(K, kLU);
+            a.b = b;
+            a.n_macro = (uint32_t)(1u << (p->N - K - LT));
+            const uint64_t total = (uint64_t)a.n_macro * ns;
+            const int inm = (i == 0) ? (vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM) : IN_WORK;
+            const int outm = (i == p->npass - 1) ? (vec_out ? OUT_SCATTER_VEC : OUT_SCATTER_ELEM) : OUT_WORK;
+            if (i == 0) a.swz_group = (a.n_macro % 8 == 0) ? ns : 0;
+            else a.swz_group = (total % 16 == 0) ? 2 : 0;
+            rc = launch(K, inm, outm, a, st);
+            if (rc) return rc;
+            b += K;
+        }
+    }
+    return ZMLS_OK;
+}
+
+int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
+                      int64_t ch_stride, void *h, int64_t out_row_stride, int64_t out_ch_stride)
+{
+    if (!p || !x || !h) { set_error("null argument"); return ZMLS_E_ARG; }
+    const size_t is = dtype_size(in_dtype), ts = dtype_size(p->dtype);
+    if (!is) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
+    if (n_ch < 1 || n_rows < 1 || row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
+    if (n_rows <= p->L) { set_error("The first sequence will be thrown away: need more than L=%lld frames", (long long)p->L); return ZMLS_E_ARG; }
+    if (n_rows % p->L) { set_error("frame count %lld is not a multiple of L=%lld", (long long)n_rows, (long long)p->L); return ZMLS_E_ARG; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    rc = zmls_plan_reserve(p, n_ch);
+    if (rc) return rc;
+    const size_t in_span = (size_t)((n_rows - 1) * row_stride + (n_ch - 1) * ch_stride + 1) * is;
+    const size_t out_span = (size_t)((p->L - 1) * out_row_stride + (n_ch - 1) * out_ch_stride + 1) * ts;
+    void *d_x = nullptr, *d_h = nullptr;
+    hipError_t e = hipMalloc(&d_x, in_span);
+    if (e == hipSuccess) e = hipMalloc(&d_h, out_span);
+    if (e == hipSuccess) e = hipMemcpy(d_x, x, in_span, hipMemcpyHostToDevice);
+    // the output may be a strided view: keep the bytes between the elements we own
+    if (e == hipSuccess) e = hipMemcpy(d_h, h, out_span, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "impulse_host staging");
+    if (!rc) rc = zmls_impulse_device(p, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride, nullptr);
+    if (!rc) {
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(h, d_h, out_span, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "impulse_host download");
+    }
+    if (d_x) (void)hipFree(d_x);
+    if (d_h) (void)hipFree(d_h);
+    return rc;
+}
+
+int zmls_average_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
+                      int64_t ch_stride, void *out)
+{
+    if (!p || !x || !out) { set_error("null argument"); return ZMLS_E_ARG; }
+    const size_t is = dtype_size(in_dtype);
+    if (!is) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
+    if (n_ch < 1 || row_stride < 1 || ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
+    if (n_rows <= p->L || n_rows % p->L) { set_error("frame count %lld must be a multiple of L=%lld and larger than L", (long long)n_rows, (long long)p->L); return ZMLS_E_ARG; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    const size_t os = (in_dtype == ZMLS_F32) ? 4 : 8;
+    const size_t in_span = (size_t)((n_rows - 1) * row_stride + (n_ch - 1) * ch_stride + 1) * is;
+    const size_t out_bytes = (size_t)p->L * n_ch * os;
+    void *d_x = nullptr, *d_o = nullptr;
+    hipError_t e = hipMalloc(&d_x, in_span);
+    if (e == hipSuccess) e = hipMalloc(&d_o, out_bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_x, x, in_span, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "average_host staging");
+    if (!rc) rc = launch_average(d_x, in_dtype, p->L, n_rows / p->L - 1, n_ch, row_stride, ch_stride, d_o, 0);
+    if (!rc) {
+        e = hipMemcpy(out, d_o, out_bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "average_host download");
+    }
+    if (d_x) (void)hipFree(d_x);
+    if (d_o) (void)hipFree(d_o);
+    return rc;
+}
+
+int zmls_synth_device(zmls_plan *p, void *d_x, int dtype, int64_t repeats, int64_t n_ch, int64_t ch_first, int64_t row_stride,
+                      int64_t ch_stride, uint64_t seed, double sigma, void *stream)
+{
+    if (!p || !d_x || repeats < 1 || n_ch < 1 || row_stride < 1 || ch_stride < 1) { set_error("bad synth arguments"); return ZMLS_E_ARG; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    return launch_synth(p->d_bits, p->L, d_x, dtype, repeats, n_ch, ch_first, row_stride, ch_stride, seed, sigma, (hipStream_t)stream);
+}
+
+int zmls_synth_system(const zmls_plan *p, int64_t channel, uint64_t seed, double *taps16, int64_t *delay)
+{
+    if (!p || !taps16 || !delay) { set_error("null argument"); return ZMLS_E_ARG; }
+    synth_system(p->L, channel, seed, taps16, delay);
+    return ZMLS_OK;
+}
+
+int zmls_plan_export_table(zmls_plan *p, int which, uint32_t *out)
+{
+    if (!p || !out || which < 0 || which > 1) { set_error("bad export arguments"); return ZMLS_E_ARG; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    ZHIP(hipMemcpy(out, which == 0 ? p->d_gather : p->d_scatter_nat, ((size_t)1 << p->N) * 4, hipMemcpyDeviceToHost));
+    return ZMLS_OK;
+}
+
+// ---- thin HIP wrappers for ctypes callers ---------------------------------------------------
+int zmls_dev_alloc(int device, void **d_ptr, size_t bytes)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipMalloc(d_ptr, bytes));
+    return ZMLS_OK;
+}
+int zmls_dev_free(int device, void *d_ptr)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipFree(d_ptr));
+    return ZMLS_OK;
+}
+int zmls_dev_upload(int device, void *d_dst, const void *src, size_t bytes)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return ZMLS_OK;
+}
+int zmls_dev_download(int device, void *dst, const void *d_src, size_t bytes)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return ZMLS_OK;
+}
+int zmls_dev_memset(int device, void *d_ptr, int value, size_t bytes)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipMemset(d_ptr, value, bytes));
+    return ZMLS_OK;
+}
+int zmls_dev_sync(int device)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipDeviceSynchronize());
+    return ZMLS_OK;
+}
+int zmls_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipMemGetInfo(free_bytes, total_bytes));
+    return ZMLS_OK;
+}
+int zmls_stream_create(int device, void **stream)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipStream_t s;
+    ZHIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return ZMLS_OK;
+}
+int zmls_stream_destroy(int device, void *stream)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipStreamDestroy((hipStream_t)stream));
+    return ZMLS_OK;
+}
+int zmls_stream_sync(int device, void *stream)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipStreamSynchronize((hipStream_t)stream));
+    return ZMLS_OK;
+}
+int zmls_event_create(int device, void **event)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipEvent_t ev;
+    ZHIP(hipEventCreate(&ev));
+    *event = (void *)ev;
+    return ZMLS_OK;
+}
+int zmls_event_destroy(int device, void *event)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipEventDestroy((hipEvent_t)event));
+    return ZMLS_OK;
+}
+int zmls_event_record(int device, void *event, void *stream)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return ZMLS_OK;
+}
+int zmls_event_elapsed_ms(int device, void *start, void *stop, float *ms)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipEventSynchronize((hipEvent_t)stop));
+    ZHIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return ZMLS_OK;
+}
+int zmls_dev_download_channel(int device, void *dst, const void *d_src, int dtype, int64_t n_rows, int64_t row_stride,
+                              int64_t ch_stride, int64_t channel)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    const size_t es = dtype_size(dtype);
+    if (!es) { set_error("bad dtype"); return ZMLS_E_ARG; }
+    void *d_tmp = nullptr;
+    ZHIP(hipMalloc(&d_tmp, (size_t)n_rows * es));
+    rc = launch_extract_channel(d_tmp, d_src, dtype, n_rows, row_stride, ch_stride, channel, 0);
+    if (!rc) {
+        hipError_t e = hipMemcpy(dst, d_tmp, (size_t)n_rows * es, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "download_channel");
+    }
+    (void)hipFree(d_tmp);
+    return rc;
+}
+
+} // extern "C"

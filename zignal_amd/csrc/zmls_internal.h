@@ -1,0 +1,119 @@
+// Internal declarations shared by the translation units of libzmls.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/zmls.h"
+#include "geometry.h"
+
+namespace zmls {
+
+constexpr uint32_t kSentinel = 0xFFFFFFFFu;
+constexpr int kLU = 2;                 // 4 vectors = 64 bytes per row segment of a slab
+constexpr int kSynthTaps = 16;
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+#define ZHIP(call)                                                         \
+    do {                                                                   \
+        hipError_t e__ = (call);                                           \
+        if (e__ != hipSuccess) return ::zmls::hip_fail(e__, #call);        \
+    } while (0)
+
+// ---- GF(2) linear maps on N-bit states (N <= 32), column form: col[i] = A * e_i
+struct Gf2Map { uint32_t col[32]; };
+ZHD uint32_t gf2_apply(const Gf2Map &A, uint32_t s, int N)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < N; ++i) r ^= A.col[i] & (0u - ((s >> i) & 1u));
+    return r;
+}
+// Fibonacci register: bit i of the state is sequence bit (n+i). One step drops bit 0 and
+// appends parity(state & G) on top. G has bit (N-t) set for every tap t.
+ZHD uint32_t fib_step(uint32_t s, uint32_t G, int N)
+{
+    return (s >> 1) | ((uint32_t)(__builtin_popcount(s & G) & 1) << (N - 1));
+}
+// Galois (dual) register: C[k+1] = x*C[k] mod p(x); C[k] are the coefficients of sequence bit
+// (n+k) in terms of bits n..n+N-1.
+ZHD uint32_t gal_step(uint32_t c, uint32_t G, int N)
+{
+    const uint32_t top = (c >> (N - 1)) & 1u;
+    const uint32_t mask = (N == 32) ? 0xFFFFFFFFu : ((1u << N) - 1u);
+    return ((c << 1) & mask) ^ (G & (0u - top));
+}
+struct JumpTables {
+    Gf2Map fib[32];   // fib[k] = F^(2^k)
+    Gf2Map gal[32];   // gal[k] = Gm^(2^k)
+};
+void build_jump_tables(int N, uint32_t G, JumpTables *jt);            // host
+uint32_t host_fib_state(int N, uint32_t G, const JumpTables &jt, uint64_t steps);
+
+// ---- pass launch description
+enum InMode { IN_WORK = 0, IN_GATHER_VEC = 1, IN_GATHER_ELEM = 2 };
+enum OutMode { OUT_WORK = 0, OUT_SCATTER_VEC = 1, OUT_SCATTER_ELEM = 2 };
+
+struct PassArgs {
+    int N;                    // transform order
+    int b;                    // bit offset of this pass
+    int single;               // 1: the whole transform is this pass; tile bits select extra slabs
+    uint32_t n_macro;         // macro tiles per slab (single: 1)
+    uint32_t n_slab_groups;   // slabs (single: groups of 2^LT slabs) in this launch
+    uint32_t swz_group;       // XCD swizzle group size (0 = identity)
+    void *work;               // [slab][2^N rows][4 vectors]
+    // gather-in
+    const void *x;
+    int in_dtype;
+    int periods;              // R - 1 averaged periods
+    int64_t L;
+    int64_t row_stride, ch_stride;   // elements
+    int64_t n_ch;             // channels of the capture
+    int64_t ch_first;         // first channel handled by slab 0 of this launch
+    const uint32_t *gather;   // Q, natural order
+    // scatter-out
+    void *h;
+    int64_t out_row_stride, out_ch_stride;
+    const uint32_t *scatter;  // last pass's thread order (single: natural order)
+};
+
+int launch_pass_f64(int K, int inm, int outm, const PassArgs &a, hipStream_t st);
+int launch_pass_f32(int K, int inm, int outm, const PassArgs &a, hipStream_t st);
+
+// ---- plan-time kernels (lfsr.hip)
+int launch_lfsr_tables(int N, uint32_t G, uint32_t s0, const JumpTables *d_jt, uint32_t *d_bits,
+                       uint64_t n_words, uint32_t *d_gather, uint32_t *d_scatter_nat, hipStream_t st);
+int launch_scatter_perm(int N, int K, int LU, int b, const uint32_t *d_scatter_nat, uint32_t *d_scatter_perm,
+                        hipStream_t st);
+int launch_sequence_expand(const uint32_t *d_bits, int64_t L, void *d_out, int dtype, int64_t repeats,
+                           int64_t stride, hipStream_t st);
+int launch_synth(const uint32_t *d_bits, int64_t L, void *d_x, int dtype, int64_t repeats, int64_t n_ch,
+                 int64_t ch_first, int64_t row_stride, int64_t ch_stride, uint64_t seed, double sigma,
+                 hipStream_t st);
+int launch_average(const void *d_x, int in_dtype, int64_t L, int64_t periods, int64_t n_ch, int64_t row_stride,
+                   int64_t ch_stride, void *d_out, hipStream_t st);
+void synth_system(int64_t L, int64_t channel, uint64_t seed, double *taps, int64_t *delay);
+int launch_extract_channel(void *d_dst, const void *d_src, int dtype, int64_t n_rows, int64_t row_stride,
+                           int64_t ch_stride, int64_t channel, hipStream_t st);
+
+} // namespace zmls
+
+struct zmls_plan {
+    int N;
+    int64_t L;
+    int ntaps;
+    int32_t taps[32];
+    uint32_t G;
+    int dtype;
+    int device;
+    int npass;
+    int bits[4];
+    uint32_t s0;                  // Fibonacci state at n = 0 (first N sequence bits)
+    uint32_t *d_bits;             // packed sequence bits, n_words uint32
+    uint64_t n_words;
+    uint32_t *d_gather;           // Q[d], 2^N
+    uint32_t *d_scatter_nat;      // M[d], 2^N
+    uint32_t *d_scatter_perm;     // M in the last pass's thread order (multi-pass plans)
+    zmls::JumpTables *d_jt;
+    void *d_work;
+    size_t work_bytes;
+};

@@ -1,0 +1,185 @@
+"""Device-resident plans and buffers: the additive, batched face of the library
+(no counterpart in the reference, whose MLS class is single-channel and
+host-only, mls.py:338-343). `zignal_amd.measure.mls` is built on top of this.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes owned by Python."""
+
+    def __init__(self, nbytes, device=0):
+        self.device = device
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        L.check(L.lib().zmls_dev_alloc(device, ctypes.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        L.check(L.lib().zmls_dev_upload(self.device, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        L.check(L.lib().zmls_dev_download(self.device, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def fill(self, byte=0):
+        L.check(L.lib().zmls_dev_memset(self.device, self.ptr, byte, self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            L.lib().zmls_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+class Plan:
+    """One (N, taps, dtype, device) plan: packed bit sequence, gather/scatter
+    tables and the FWHT workspace live on the GPU for its lifetime."""
+
+    def __init__(self, N, taps, dtype="f64", device=None):
+        self.device = L.default_device() if device is None else int(device)
+        self.dtype_code = {"f64": L.ZMLS_F64, "f32": L.ZMLS_F32}[dtype]
+        self.np_dtype = L.NP_OF[self.dtype_code]
+        self.N = int(N)
+        self.L = (1 << self.N) - 1
+        self.taps = tuple(int(t) for t in taps)
+        arr, n = L.taps_array(self.taps)
+        h = ctypes.c_void_p()
+        L.check(L.lib().zmls_plan_create(ctypes.byref(h), self.N, arr, n, self.dtype_code, self.device))
+        self._h = h
+
+    # -- housekeeping
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().zmls_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def info(self):
+        buf = (ctypes.c_int64 * 16)()
+        L.check(L.lib().zmls_plan_info(self._h, buf))
+        v = list(buf)
+        return {"N": v[0], "L": v[1], "dtype": v[2], "device": v[3], "passes": v[4],
+                "pass_bits": [b for b in v[5:8] if b], "workspace_bytes": v[8], "channels_per_slab": v[9]}
+
+    def reserve(self, n_ch):
+        L.check(L.lib().zmls_plan_reserve(self._h, int(n_ch)))
+
+    # -- sequence
+    def bits_packed(self, nbits=None):
+        nbits = self.L if nbits is None else int(nbits)
+        out = np.zeros((nbits + 7) // 8, dtype=np.uint8)
+        L.check(L.lib().zmls_sequence_bits(self._h, out.ctypes.data, nbits))
+        return out
+
+    def sequence(self, repeats=1):
+        out = np.empty((repeats * self.L, 1), dtype=np.float64)
+        L.check(L.lib().zmls_sequence_f64(self._h, out.ctypes.data, int(repeats)))
+        return out
+
+    def tables(self):
+        n = 1 << self.N
+        q = np.empty(n, dtype=np.uint32)
+        m = np.empty(n, dtype=np.uint32)
+        L.check(L.lib().zmls_plan_export_table(self._h, 0, q.ctypes.data))
+        L.check(L.lib().zmls_plan_export_table(self._h, 1, m.ctypes.data))
+        return q, m
+
+    # -- impulse responses
+    def impulse_host(self, x):
+        """x: ndarray (R*L,) or (R*L, C), any strides; returns (L, C) of the plan dtype."""
+        x2, code, n_rows, n_ch, rs, cs = self._as_capture(x)
+        h = np.empty((self.L, n_ch), dtype=self.np_dtype)
+        L.check(L.lib().zmls_impulse_host(self._h, x2.ctypes.data, code, n_rows, n_ch, rs, cs,
+                                          h.ctypes.data, n_ch, 1))
+        return h
+
+    @staticmethod
+    def _as_capture(x):
+        """ndarray -> (array kept alive, dtype code, frames, channels, row stride, channel stride)"""
+        x2 = x.reshape(-1, 1) if x.ndim == 1 else x
+        if x2.ndim != 2:
+            raise ValueError("captures are (frames,) or (frames, channels)")
+        code = L.dtype_code(x2.dtype)
+        if code is None:
+            x2 = np.ascontiguousarray(x2, dtype=np.float64)
+            code = L.ZMLS_F64
+        es = x2.dtype.itemsize
+        # ctypes.data of a positive-stride view is its lowest address; anything else is copied
+        if x2.strides[0] % es or x2.strides[1] % es or x2.strides[0] <= 0 or x2.strides[1] <= 0:
+            x2 = np.ascontiguousarray(x2)
+        return x2, code, x2.shape[0], x2.shape[1], x2.strides[0] // es, x2.strides[1] // es
+
+    def average_host(self, x):
+        """Periods 1..R-1 of x averaged -> (L, C); float32 in float32, everything else in float64."""
+        x2, code, n_rows, n_ch, rs, cs = self._as_capture(x)
+        out = np.empty((self.L, n_ch), dtype=np.float32 if code == L.ZMLS_F32 else np.float64)
+        L.check(L.lib().zmls_average_host(self._h, x2.ctypes.data, code, n_rows, n_ch, rs, cs, out.ctypes.data))
+        return out
+
+    def impulse_device(self, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h,
+                       out_row_stride, out_ch_stride, stream=None):
+        L.check(L.lib().zmls_impulse_device(self._h, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride,
+                                            d_h, out_row_stride, out_ch_stride, stream))
+
+    def synth_device(self, d_x, dtype_code, repeats, n_ch, row_stride, ch_stride, seed=0x5A17,
+                     sigma=1e-3, ch_first=0, stream=None):
+        L.check(L.lib().zmls_synth_device(self._h, d_x, dtype_code, repeats, n_ch, ch_first, row_stride,
+                                          ch_stride, seed, sigma, stream))
+
+    def synth_system(self, channel, seed=0x5A17):
+        taps = (ctypes.c_double * 16)()
+        d = ctypes.c_int64()
+        L.check(L.lib().zmls_synth_system(self._h, channel, seed, taps, ctypes.byref(d)))
+        return np.array(list(taps)), d.value
+
+
+def sync(device=0):
+    L.check(L.lib().zmls_dev_sync(device))
+
+
+def download_channel(device, d_src, dtype_code, n_rows, row_stride, ch_stride, channel):
+    out = np.empty(n_rows, dtype=L.NP_OF[dtype_code])
+    L.check(L.lib().zmls_dev_download_channel(device, out.ctypes.data, d_src, dtype_code, n_rows,
+                                              row_stride, ch_stride, channel))
+    return out
+
+
+class Timer:
+    """HIP events on one stream (bench.py)."""
+
+    def __init__(self, device=0):
+        self.device = device
+        self.a, self.b = ctypes.c_void_p(), ctypes.c_void_p()
+        L.check(L.lib().zmls_event_create(device, ctypes.byref(self.a)))
+        L.check(L.lib().zmls_event_create(device, ctypes.byref(self.b)))
+
+    def start(self, stream=None):
+        L.check(L.lib().zmls_event_record(self.device, self.a, stream))
+
+    def stop(self, stream=None):
+        L.check(L.lib().zmls_event_record(self.device, self.b, stream))
+
+    def elapsed_ms(self):
+        ms = ctypes.c_float()
+        L.check(L.lib().zmls_event_elapsed_ms(self.device, self.a, self.b, ctypes.byref(ms)))
+        return ms.value

@@ -1,0 +1,46 @@
+"""The slice of zignal's `Filter` that the MLS emphasis / de-emphasis step uses
+(zignal/filters/linearfilter.py:28-143): coefficient holder, `filter_samples`
+(= scipy.signal.lfilter along axis 0) and the minimum-phase test MLS asserts on
+(zignal/measure/mls.py:365-369). Runs on the host; moving it onto the device is
+the first "next" row of SURVEY.md §8(f).
+"""
+import numpy as np
+import scipy.signal
+
+
+class Filter(object):
+    def __init__(self, B=None, A=None, fs=96000):
+        assert fs > 0
+        self.fs = fs
+        self.set_coefficients(B=B, A=A)
+
+    def set_coefficients(self, B=None, A=None):
+        self._B = np.array((1,)) if B is None else np.array(B)
+        self._A = np.array((1,)) if A is None else np.array(A)
+        assert len(self._B) != 0
+        assert len(self._A) != 0
+
+    def get_coefficients(self):
+        return self._B, self._A
+
+    def normalise(self):
+        a0 = self._A[0]
+        self._B = self._B / a0
+        self._A = self._A / a0
+
+    def filter_samples(self, samples):
+        return scipy.signal.lfilter(self._B, self._A, samples, axis=0)
+
+    def _zeros_poles(self):
+        z, p, _ = scipy.signal.tf2zpk(self._B, self._A)
+        return z, p
+
+    def is_stable(self):
+        return bool(np.all(np.abs(self._zeros_poles()[1]) < 1.0))
+
+    def is_minimum_phase(self):
+        z, p = self._zeros_poles()
+        return bool(np.all(np.abs(p) < 1.0) and np.all(np.abs(z) < 1.0))
+
+    def __repr__(self):
+        return "Filter(B=%s, A=%s, fs=%s)" % (list(self._B), list(self._A), self.fs)

@@ -1,0 +1,229 @@
+"""MLS generation and impulse-response extraction on the GPU, behind the API of
+`zignal.measure.mls` (zignal v0.6.0). Class names, method names (including the
+reference's spelling `trim_and_avgerage`), argument meaning, return shapes/dtypes and
+exception types follow zignal/measure/mls.py; each method cites the lines it replaces.
+
+What runs where
+    sequence bits, +1/-1 stimulus ........ HIP kernel (lfsr.hip), once per (N, taps) plan
+    drop period 0 + average + circular
+    cross-correlation + /L ............... HIP kernels (fwht_kernels.inc): gather -> FWHT -> scatter
+    emphasis / de-emphasis IIR ........... host, scipy.signal.lfilter (as the reference)
+There is no CPU implementation of the first two groups in this package.
+"""
+import logging
+import random
+
+import numpy as np
+
+from ..audio import Audio
+from ..device import Plan
+from ..filters.biquads import RBJ
+from ..filters.linearfilter import Filter
+from .mlstaps import TAPS  # noqa: F401  (re-exported, as the reference does at mls.py:24)
+
+__all__ = ['MLS', 'MLS_simple', 'get_random_taps', 'TAPS']
+
+
+def get_random_taps(N):
+    '''Select a random set of taps for given order N (mls.py:34-36)'''
+    return random.choice(TAPS.get(N))
+
+
+class _MLS_base(object):
+    """Sequence generators, circular cross-correlation and impulse-response extraction
+    (mls.py:39-328). Independent of any sample rate.
+
+    Extra keyword arguments (additive, defaults preserve the reference's behaviour):
+    `dtype` 'f64' (reference arithmetic) or 'f32'; `device` HIP device ordinal
+    (default: $ZMLS_DEVICE, else $LOCAL_RANK, else 0).
+    """
+
+    def __init__(self, N=None, taps=None, dtype='f64', device=None):
+        # mls.py:65-68
+        assert N is not None, "Please specify MLS order"
+        assert taps is not None, "Please specify feedback taps"
+        assert isinstance(taps, (tuple, list))
+        assert len(taps) != 0, "taps are empty!"
+
+        self._logger = logging.getLogger(__name__)
+        self.N = N
+        self.L = (2**N) - 1
+        self.taps = taps
+        self._RAM_usage = (self.L * np.int64().dtype.itemsize) / (1024**2)     # in Mb, mls.py:75-76
+        self._dtype = dtype
+        self._device = device
+        self._plan_obj = None
+        self._period_bits = None
+
+    # ---- device plan (built on first use, then kept: the reference regenerates the whole
+    # sequence on every call, mls.py:207)
+    def _plan(self):
+        if self._plan_obj is None:
+            self._plan_obj = Plan(self.N, self.taps, dtype=self._dtype, device=self._device)
+        return self._plan_obj
+
+    def _bits(self):
+        if self._period_bits is None:
+            packed = self._plan().bits_packed()
+            self._period_bits = np.unpackbits(packed, bitorder="little")[:self.L].astype(np.int64)
+        return self._period_bits
+
+    def __repr__(self):
+        return '_MLS_base(N=%i, taps=%s)' % (self.N, tuple(self.taps))
+
+    def __str__(self):
+        s  = '=======================================\n'
+        s += 'classname        : %s\n' % self.__class__.__name__
+        s += 'N                : %i\n' % self.N
+        s += 'L=(2^N)-1        : %i\n' % self.L
+        s += 'taps             : %s\n' % str(self.taps)
+        s += "RAM              : %.1f [Mb] (one full sequence)\n" % self._RAM_usage
+        s += '-----------------:---------------------\n'
+        return s
+
+    # ---- generators (mls.py:91-152). The bits come from the device plan; the generators only
+    # hand them out, endlessly, wrapping at L as the shift register does.
+    def generator_bit(self):
+        bits = self._bits()
+        i = 0
+        while True:
+            yield int(bits[i])
+            i = i + 1 if i + 1 < self.L else 0
+
+    def generator_chunk(self, chunk=1024):
+        bits = self._bits()
+        pos = 0
+        while True:
+            idx = (pos + np.arange(chunk)) % self.L
+            pos = (pos + chunk) % self.L
+            yield bits[idx].reshape(chunk, 1)
+
+    def generator_samples(self, chunk=1024):
+        for block in self.generator_chunk(chunk):
+            yield (1.0 - 2.0 * block).astype(np.float64)     # bit 0 -> +1.0, bit 1 -> -1.0 (mls.py:150)
+
+    def get_full_sequence(self, repeats=1):
+        """(repeats*L, 1) float64 stimulus (mls.py:154-167)."""
+        return self._plan().sequence(repeats)
+
+    # ---- impulse-response extraction
+    def _one_channel(self, other):
+        """Reject what the reference's reshape rejects (mls.py:294-298), with its message."""
+        trimmed_size = other[self.L:].size
+        periods = len(other[self.L:]) // self.L
+        if trimmed_size != periods * self.L:
+            raise ValueError("cannot reshape array of size %d into shape (%d,%d)" % (trimmed_size, periods, self.L))
+        return periods
+
+    def trim_and_avgerage(self, other):
+        """Drop the first period, average the others -> (L, 1) (mls.py:258-313). On the device;
+        float32 captures are averaged and returned in float32 like numpy does, everything else
+        in float64."""
+        self._one_channel(other)
+        return self._plan().average_host(other)
+
+    def xcorr_circular(self, other):
+        """Circular cross-correlation of one period `other` ((L,) or (L,1)) with the sequence,
+        normalised by L -> (L, 1) float64 (mls.py:169-256)."""
+        other = np.asarray(other)
+        one = other.reshape(-1)
+        if one.shape[0] != self.L:
+            raise ValueError("input must hold exactly one period of %d samples" % self.L)
+        # the device entry point averages periods 1..R-1; feed it the period twice
+        h = self._plan().impulse_host(np.concatenate((one, one)))
+        return h.astype(np.float64, copy=False)
+
+    def get_impulse(self, x):
+        """Impulse response (L, 1) float64 from a capture of R >= 2 periods (mls.py:315-328)."""
+        assert isinstance(x, np.ndarray)
+        assert len(x) > self.L, "The first sequence will be thrown away"
+        self._one_channel(x)
+        h = self._plan().impulse_host(x)
+        return h.astype(np.float64, copy=False)
+
+    # ---- additive: many channels at once (the reference is single-channel, mls.py:338-343)
+    def get_impulses(self, x):
+        """x: (R*L, C) -> (L, C): every column is treated as get_impulse treats its input."""
+        assert isinstance(x, np.ndarray) and x.ndim == 2
+        assert len(x) > self.L, "The first sequence will be thrown away"
+        if len(x) % self.L:
+            raise ValueError("number of frames %d is not a multiple of L=%d" % (len(x), self.L))
+        return self._plan().impulse_host(x)
+
+
+class MLS(_MLS_base, Audio):
+    """MLS stimulus as an `Audio` (one channel) plus emphasis / de-emphasis filters
+    (mls.py:331-414)."""
+
+    def __init__(self, N=None, taps=None, fs=96000, repeats=2, B=(1, 0, 0), A=(1, 0, 0), dtype='f64', device=None):
+        assert repeats > 1, "at least two sequences are needed, (repeats=2)"
+
+        _MLS_base.__init__(self, N=N, taps=taps, dtype=dtype, device=device)
+        Audio.__init__(self, fs=fs, initialdata=self.get_full_sequence(repeats=repeats))
+
+        self.repeats = repeats
+        self._length_impresp = self.L / self.fs
+        self._filter_emphasis = Filter(B=B, A=A, fs=self.fs)
+        self._filter_deemphasis = Filter(B=A, A=B, fs=self.fs)      # inverse filter
+
+        assert self._filter_emphasis.is_minimum_phase(), \
+            "The emphasis filter must be minimum phase, i.e. possible to invert"
+
+    def __repr__(self):
+        B, A = self._filter_emphasis.get_coefficients()
+        return 'MLS(N=%i, taps=%s, fs=%r, repeats=%i, B=%s, A=%s)' \
+            % (self.N, tuple(self.taps), self.fs, self.repeats, tuple(B), tuple(A))
+
+    def __str__(self):
+        B, A = self._filter_emphasis.get_coefficients()
+        base = "\n".join(_MLS_base.__str__(self).splitlines()[2:-1])
+        s  = Audio.__str__(self)
+        s += '%s\n' % base
+        s += 'repeats          : %i\n' % self.repeats
+        s += 'len(impulse)     : %.3f [s]\n' % self._length_impresp
+        s += 'emphasis filt. B : %s\n' % str(B)
+        s += 'emphasis filt. A : %s\n' % str(A)
+        return s
+
+    def apply_emphasis(self):
+        """Filter the stimulus in place with the emphasis filter (mls.py:393-399)."""
+        self.samples = self._filter_emphasis.filter_samples(self.samples)
+
+    def apply_deemphasis(self, x):
+        """Filter a capture with the inverse of the emphasis filter (mls.py:401-407)."""
+        return self._filter_deemphasis.filter_samples(x)
+
+    def get_impulse(self, x):
+        """Impulse response as an `Audio` (mls.py:409-414)."""
+        imp = _MLS_base.get_impulse(self, x)
+        return Audio(fs=self.fs, initialdata=imp)
+
+
+class MLS_simple(object):
+    """MLS with a -10 dB high-shelf emphasis at 100 Hz, applied and undone for the caller
+    (mls.py:417-466)."""
+
+    def __init__(self, N=16, fs=96000, repeats=3, dtype='f64', device=None):
+        B, A = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=fs).get_coefficients()
+        self._mls = MLS(N=N, taps=TAPS[N][0], fs=fs, repeats=repeats, B=B, A=A, dtype=dtype, device=device)
+        self._mls.apply_emphasis()
+        self.samples = self._mls.samples
+
+    def __repr__(self):
+        return 'MLS_simple(N=%i fs=%r, repeats=%i)' % (self._mls.N, self._mls.fs, self._mls.repeats)
+
+    def __str__(self):
+        body = "\n".join(str(self._mls).splitlines()[2:])
+        s  = '=======================================\n'
+        s += 'classname        : %s\n' % self.__class__.__name__
+        s += '%s' % body
+        return s
+
+    def get_impulse(self, x):
+        tmp = self._mls.apply_deemphasis(x)
+        self._impulseresponse = self._mls.get_impulse(tmp)
+        return self._impulseresponse
+
+    def plot_fft(self, plotname=None):
+        assert hasattr(self, "_impulseresponse"), "call get_impulse(...) before trying to plot"
+        self._impulseresponse.plot_fft(plotname=plotname, window='rectangular', normalise=False)
