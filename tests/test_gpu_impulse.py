@@ -59,8 +59,9 @@ def test_golden_ir_large(case):
     assert np.max(np.abs(h[lo:lo + 256] - arrays[k + "_peakwin"])) <= tol
     assert int(np.argmax(np.abs(h))) == case["argmax"]
     assert abs(float(h[case["argmax"]]) - case["max"]) <= tol
-    assert abs(float(np.sum(h)) - case["sum"]) <= 1e-9 * max(1.0, abs(case["sum"]))
-    assert abs(float(np.sum(h * h)) - case["sumsq"]) <= 1e-9 * case["sumsq"]
+    agg = 1e-5 if case["dtype"] == "float32" else 1e-9      # float32 captures: see module docstring
+    assert abs(float(np.sum(h)) - case["sum"]) <= agg * max(1.0, abs(case["sum"]))
+    assert abs(float(np.sum(h * h)) - case["sumsq"]) <= agg * case["sumsq"]
     if case["N"] <= 20 and case["dtype"] == "float64":
         h32 = plan(case["N"], case["taps"], "f32").impulse_host(x)[:, 0]
         assert np.max(np.abs(h32[arrays[k + "_idx"]] - arrays[k + "_h"])) <= TOL32 * case["peak"]
