@@ -57,8 +57,12 @@ int zmls_plan_destroy(zmls_plan *p);
 /* Make sure the workspace can hold `n_ch` channels in one go (allocates; call outside timed/captured regions). */
 int zmls_plan_reserve(zmls_plan *p, int64_t n_ch);
 /* info[0]=N info[1]=L info[2]=dtype info[3]=device info[4]=number of FWHT passes
- * info[5..7]=bits per pass info[8]=workspace bytes info[9]=channels per slab */
+ * info[5..7]=bits per pass info[8]=workspace bytes info[9]/info[10]=channels per slab of the small/big tile */
 int zmls_plan_info(const zmls_plan *p, int64_t info[16]);
+/* Tile configuration used by the impulse entry points: -1 = chosen per call (default), 0 = small tile
+ * (64 KiB, 64-byte row segments, any layout), 1 = big tile (256 KiB, 256-byte row segments; needs
+ * contiguous, 16-byte aligned channels). For tests and tuning. */
+int zmls_plan_force_tile(zmls_plan *p, int cfg);
 
 /* ---- sequence: replaces generator_bit / generator_chunk / generator_samples /
  * get_full_sequence (mls.py:91-167). */
@@ -81,6 +85,13 @@ int zmls_sequence_device(zmls_plan *p, void *d_out, int dtype, int64_t repeats, 
 int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch,
                         int64_t row_stride, int64_t ch_stride,
                         void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
+/* profiling variant (bench.py): same launches with a HIP event either side of every pass kernel on
+ * `hip_stream`; synchronises and returns the milliseconds of pass i in pass_ms[i] (summed over channel
+ * chunks). Creates and destroys its events: not for timed or captured regions. */
+int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch,
+                              int64_t row_stride, int64_t ch_stride,
+                              void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream,
+                              float pass_ms[4]);
 /* host buffers: uploads, runs, downloads, synchronous. h element type = plan dtype. */
 int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch,
                       int64_t row_stride, int64_t ch_stride,
@@ -137,7 +148,7 @@ int zmls_host_pass_split(int N, int bits[4]);
 int zmls_host_lfsr_state(int N, const int32_t *taps, int ntaps, uint64_t steps, uint32_t *state);
 /* enumerate the tile geometry of one pass and verify every element is covered exactly once per round and
  * every LDS slot / workspace row is in range; returns 0 if consistent. */
-int zmls_host_geometry_selfcheck(int K, int log2_units, int first_pass);
+int zmls_host_geometry_selfcheck(int K, int tile_cfg, int first_pass);
 
 #ifdef __cplusplus
 }

@@ -217,3 +217,32 @@ def test_mls_and_mls_simple_classes_against_reference_goldens():
     assert rel_err(ir.samples, arrays["simple_ir"]) <= TOL64
     with pytest.raises(AssertionError):
         MLS(5, (5, 3), repeats=2, B=(1, 2, 0), A=(1, 0, 0), device=0)      # not minimum phase
+
+
+@pytest.mark.parametrize("N,C,dtype", [(11, 32, "f64"), (12, 64, "f64"), (13, 96, "f64"), (15, 40, "f64"), (16, 64, "f64"),
+                                        (17, 32, "f64"), (18, 64, "f64"), (19, 32, "f64"), (20, 32, "f64"), (21, 32, "f64"),
+                                        (14, 64, "f32"), (18, 128, "f32"), (20, 64, "f32")])
+def test_big_tile_against_small_tile_and_oracle(N, C, dtype):
+    """Wide, contiguous channel blocks go through the 256 KiB register-resident tile (256-byte row
+    segments); the result must equal the small tile's to round-off and the oracle's within tolerance.
+    Covers 2-pass (N<=20) and 3-pass (N=21) plans and a ragged last slab (C=40, C=96)."""
+    taps = TAPS[N][0]
+    L = (1 << N) - 1
+    R = 3 if N <= 18 else 2
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    rng = np.random.default_rng(N * 1000 + C)
+    x = rng.standard_normal((R * L, C)).astype(np_dt)
+    p = plan(N, taps, dtype)
+    p.force_tile(1)
+    h_big = p.impulse_host(x)
+    p.force_tile(0)
+    h_small = p.impulse_host(x)
+    p.force_tile(-1)
+    h_auto = p.impulse_host(x)
+    assert np.array_equal(h_auto, h_big)                      # auto picks the big tile for such input
+    tol = TOL64 if dtype == "f64" else TOL32
+    assert rel_err(h_big, h_small.astype(np.float64)) <= (1e-14 if dtype == "f64" else 1e-5)
+    ref = c_oracle.sequence(N, taps)
+    for c in (0, C // 2 + 1, C - 1):
+        want = oracle_ir(N, taps, np.ascontiguousarray(x[:, c:c + 1]).astype(np.float64), ref)
+        assert rel_err(h_big[:, c], want) <= tol, (N, c)

@@ -54,8 +54,9 @@ def test_pass_split(lib):
 
 @pytest.mark.parametrize("first", [0, 1])
 @pytest.mark.parametrize("K", range(1, 11))
-def test_tile_geometry_is_a_tiling(lib, K, first):
-    assert lib.zmls_host_geometry_selfcheck(K, 2, first) == 0, _lib.last_error()
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_tile_geometry_is_a_tiling(lib, cfg, K, first):
+    assert lib.zmls_host_geometry_selfcheck(K, cfg, first) == 0, _lib.last_error()
 
 
 def _window(N, taps, steps):

@@ -30,11 +30,14 @@ SIGNATURES = {
     "zmls_plan_create": [_vpp, c_int, _i32p, c_int, c_int, c_int],
     "zmls_plan_destroy": [c_vp],
     "zmls_plan_reserve": [c_vp, c_i64],
+    "zmls_plan_force_tile": [c_vp, c_int],
     "zmls_plan_info": [c_vp, ctypes.POINTER(c_i64)],
     "zmls_sequence_bits": [c_vp, c_vp, c_i64],
     "zmls_sequence_f64": [c_vp, c_vp, c_i64],
     "zmls_sequence_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_vp],
     "zmls_impulse_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],
+    "zmls_impulse_device_timed": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp,
+                                  ctypes.POINTER(ctypes.c_float)],
     "zmls_impulse_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64],
     "zmls_average_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp],
     "zmls_synth_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_u64, ctypes.c_double, c_vp],

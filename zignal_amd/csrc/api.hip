@@ -40,15 +40,16 @@ __global__ void count_sentinels_kernel(const uint32_t *t, uint64_t n, unsigned l
     if (local) atomicAdd(count, local);
 }
 
-size_t slab_bytes(const zmls_plan *p) { return ((size_t)1 << p->N) * (kVecBytes << kLU); }
-int chans_per_slab(const zmls_plan *p) { return (int)((kVecBytes << kLU) / dtype_size(p->dtype)); }
+size_t slab_bytes(const zmls_plan *p, int cfg) { return ((size_t)1 << p->N) * (kVecBytes << kCfg[cfg].lu); }
+int chans_per_slab(const zmls_plan *p, int cfg) { return (int)((kVecBytes << kCfg[cfg].lu) / dtype_size(p->dtype)); }
 
 void free_plan_buffers(zmls_plan *p)
 {
     if (p->d_bits) (void)hipFree(p->d_bits);
     if (p->d_gather) (void)hipFree(p->d_gather);
     if (p->d_scatter_nat) (void)hipFree(p->d_scatter_nat);
-    if (p->d_scatter_perm) (void)hipFree(p->d_scatter_perm);
+    for (int c = 0; c < CFG_COUNT; ++c)
+        if (p->d_scatter_perm[c]) (void)hipFree(p->d_scatter_perm[c]);
     if (p->d_jt) (void)hipFree(p->d_jt);
     if (p->d_work) (void)hipFree(p->d_work);
 }
@@ -89,9 +90,11 @@ int build_plan(zmls_plan *p)
     if (p->npass > 1) {
         int b = 0;
         for (int i = 0; i + 1 < p->npass; ++i) b += p->bits[i];
-        ZHIP(hipMalloc((void **)&p->d_scatter_perm, n * 4));
-        rc = launch_scatter_perm(p->N, p->bits[p->npass - 1], kLU, b, p->d_scatter_nat, p->d_scatter_perm, 0);
-        if (rc) return rc;
+        for (int c = 0; c < CFG_COUNT; ++c) {
+            ZHIP(hipMalloc((void **)&p->d_scatter_perm[c], n * 4));
+            rc = launch_scatter_perm(p->N, p->bits[p->npass - 1], kCfg[c], b, p->d_scatter_nat, p->d_scatter_perm[c], 0);
+            if (rc) return rc;
+        }
     }
     ZHIP(hipDeviceSynchronize());
     return ZMLS_OK;
@@ -132,6 +135,7 @@ int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int
     p->s0 = s0;
     p->dtype = dtype;
     p->device = device;
+    p->force_cfg = -1;
     rc = build_plan(p);
     if (rc) { free_plan_buffers(p); free(p); return rc; }
     *out = p;
@@ -152,12 +156,24 @@ int zmls_plan_reserve(zmls_plan *p, int64_t n_ch)
     if (p->npass == 1) return ZMLS_OK;   // single-pass plans keep everything in LDS
     int rc = use_device(p->device);
     if (rc) return rc;
-    const int cs = chans_per_slab(p);
-    const size_t need = (size_t)((n_ch + cs - 1) / cs) * slab_bytes(p);
+    // the wider slab of the two tile configurations bounds what either needs
+    size_t need = 0;
+    for (int c = 0; c < CFG_COUNT; ++c) {
+        const int cs = chans_per_slab(p, c);
+        const size_t want = (size_t)((n_ch + cs - 1) / cs) * slab_bytes(p, c);
+        if (want > need) need = want;
+    }
     if (need <= p->work_bytes) return ZMLS_OK;
     if (p->d_work) { ZHIP(hipFree(p->d_work)); p->d_work = nullptr; p->work_bytes = 0; }
     ZHIP(hipMalloc(&p->d_work, need));
     p->work_bytes = need;
+    return ZMLS_OK;
+}
+
+int zmls_plan_force_tile(zmls_plan *p, int cfg)
+{
+    if (!p || cfg < -1 || cfg >= CFG_COUNT) { set_error("tile configuration must be -1 (auto), 0 (small) or 1 (big)"); return ZMLS_E_ARG; }
+    p->force_cfg = cfg;
     return ZMLS_OK;
 }
 
@@ -167,7 +183,7 @@ int zmls_plan_info(const zmls_plan *p, int64_t info[16])
     memset(info, 0, sizeof(int64_t) * 16);
     info[0] = p->N; info[1] = p->L; info[2] = p->dtype; info[3] = p->device; info[4] = p->npass;
     info[5] = p->bits[0]; info[6] = p->bits[1]; info[7] = p->bits[2];
-    info[8] = (int64_t)p->work_bytes; info[9] = chans_per_slab(p);
+    info[8] = (int64_t)p->work_bytes; info[9] = chans_per_slab(p, CFG_SMALL); info[10] = chans_per_slab(p, CFG_BIG);
     return ZMLS_OK;
 }
 
@@ -209,8 +225,9 @@ int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
     return ZMLS_OK;
 }
 
-int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
-                        int64_t ch_stride, void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *stream)
+static int impulse_device_impl(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
+                               int64_t ch_stride, void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *stream,
+                               hipEvent_t *ev /* 2 per pass, or null */, float *pass_ms /* accumulated, or null */)
 {
     if (!p || !d_x || !d_h) { set_error("null argument"); return ZMLS_E_ARG; }
     if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
@@ -226,14 +243,20 @@ int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_r
 
     const size_t ts = dtype_size(p->dtype);
     const int E = (int)(kVecBytes / ts);
-    const int CS = chans_per_slab(p);
-    const int64_t n_slabs = (n_ch + CS - 1) / CS;
     const bool single = p->npass == 1;
     const bool vec_in = !single && in_dtype == p->dtype && ch_stride == 1 && (row_stride * (int64_t)ts) % kVecBytes == 0 &&
                         ((uintptr_t)d_x % kVecBytes) == 0 && n_ch % E == 0;
     const bool vec_out = !single && out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 &&
                          ((uintptr_t)d_h % kVecBytes) == 0 && n_ch % E == 0;
     auto launch = (p->dtype == ZMLS_F64) ? launch_pass_f64 : launch_pass_f32;
+    // wide vector-aligned channel blocks stream through the big tile (256-byte row segments); everything
+    // else, and every single-pass order, through the small one
+    int cfg = CFG_SMALL;
+    if (vec_in && vec_out && n_ch >= chans_per_slab(p, CFG_BIG) && p->force_cfg != CFG_SMALL) cfg = CFG_BIG;
+    if (p->force_cfg == CFG_BIG && !(vec_in && vec_out)) { set_error("big tile needs vector-aligned contiguous channels"); return ZMLS_E_ARG; }
+    const TileCfg tc = kCfg[cfg];
+    const int CS = chans_per_slab(p, cfg);
+    const int64_t n_slabs = (n_ch + CS - 1) / CS;
 
     PassArgs a;
     memset(&a, 0, sizeof a);
@@ -245,21 +268,31 @@ int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_r
 
     if (single) {
         const int K = p->bits[0];
-        const int LT = log2_tiles(K, kLU);
+        const int LT = log2_tiles(K, tc);
         a.single = 1; a.b = 0; a.n_macro = 1;
         a.n_slab_groups = (uint32_t)((n_slabs + (1 << LT) - 1) >> LT);
         a.ch_first = 0;
         a.scatter = p->d_scatter_nat;
-        return launch(K, IN_GATHER_ELEM, OUT_SCATTER_ELEM, a, st);
+        if (ev) ZHIP(hipEventRecord(ev[0], st));
+        rc = launch(cfg, K, IN_GATHER_ELEM, OUT_SCATTER_ELEM, a, st);
+        if (rc) return rc;
+        if (ev) {
+            float ms = 0.f;
+            ZHIP(hipEventRecord(ev[1], st));
+            ZHIP(hipEventSynchronize(ev[1]));
+            ZHIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            pass_ms[0] += ms;
+        }
+        return ZMLS_OK;
     }
 
-    const int64_t cap = (int64_t)(p->work_bytes / slab_bytes(p));
+    const int64_t cap = (int64_t)(p->work_bytes / slab_bytes(p, cfg));
     if (cap < 1) {
-        set_error("plan workspace (%zu bytes) holds no channel slab (%zu bytes each): call zmls_plan_reserve first", p->work_bytes, slab_bytes(p));
+        set_error("plan workspace (%zu bytes) holds no channel slab (%zu bytes each): call zmls_plan_reserve first", p->work_bytes, slab_bytes(p, cfg));
         return ZMLS_E_WORKSPACE;
     }
     a.work = p->d_work;
-    a.scatter = p->d_scatter_perm;
+    a.scatter = p->d_scatter_perm[cfg];
     for (int64_t s0 = 0; s0 < n_slabs; s0 += cap) {
         const uint32_t ns = (uint32_t)((n_slabs - s0 < cap) ? n_slabs - s0 : cap);
         a.ch_first = s0 * CS;
@@ -267,20 +300,57 @@ int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_r
         int b = 0;
         for (int i = 0; i < p->npass; ++i) {
             const int K = p->bits[i];
-            const int LT = log2_tiles(K, kLU);
+            const int LT = log2_tiles(K, tc);
             a.b = b;
             a.n_macro = (uint32_t)(1u << (p->N - K - LT));
             const uint64_t total = (uint64_t)a.n_macro * ns;
             const int inm = (i == 0) ? (vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM) : IN_WORK;
             const int outm = (i == p->npass - 1) ? (vec_out ? OUT_SCATTER_VEC : OUT_SCATTER_ELEM) : OUT_WORK;
-            if (i == 0) a.swz_group = (a.n_macro % 8 == 0) ? ns : 0;
+            if (cfg == CFG_BIG) a.swz_group = 0;
+            else if (i == 0) a.swz_group = (a.n_macro % 8 == 0) ? ns : 0;
             else a.swz_group = (total % 16 == 0) ? 2 : 0;
-            rc = launch(K, inm, outm, a, st);
+            if (ev) ZHIP(hipEventRecord(ev[2 * i], st));
+            rc = launch(cfg, K, inm, outm, a, st);
             if (rc) return rc;
+            if (ev) ZHIP(hipEventRecord(ev[2 * i + 1], st));
             b += K;
         }
+        if (ev)
+            for (int i = 0; i < p->npass; ++i) {
+                float ms = 0.f;
+                ZHIP(hipEventSynchronize(ev[2 * i + 1]));
+                ZHIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+                pass_ms[i] += ms;
+            }
     }
     return ZMLS_OK;
+}
+
+int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
+                        int64_t ch_stride, void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *stream)
+{
+    return impulse_device_impl(p, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride,
+                               stream, nullptr, nullptr);
+}
+
+int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
+                              int64_t ch_stride, void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *stream,
+                              float pass_ms[4])
+{
+    if (!p || !pass_ms) { set_error("null argument"); return ZMLS_E_ARG; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    hipEvent_t ev[8];
+    int made = 0;
+    for (; made < 8; ++made)
+        if (hipEventCreate(&ev[made]) != hipSuccess) break;
+    for (int i = 0; i < 4; ++i) pass_ms[i] = 0.f;
+    if (made == 8)
+        rc = impulse_device_impl(p, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride,
+                                 stream, ev, pass_ms);
+    else { set_error("could not create HIP events"); rc = ZMLS_E_HIP; }
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }
 
 int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,

@@ -2,16 +2,23 @@
 // host-side self check (zmls_host_geometry_selfcheck), so there is exactly one definition of
 // "which thread holds which element in which round".
 //
-// A workgroup of 256 threads owns a MACRO TILE of 4096 sixteen-byte vectors (64 KiB):
-//     2^LT tiles  x  2^K rows  x  2^LU vectors per row        (LT = 12 - LU - K)
+// A workgroup owns a MACRO TILE of 2^LOGV sixteen-byte vectors:
+//     2^LT tiles  x  2^K rows  x  2^LU vectors per row        (LT = LOGV - LU - K)
 // A "vector" is 16 bytes of adjacent channels (2 doubles or 4 floats); a row of a tile is
 // 2^LU vectors = one contiguous row segment of a channel slab. The pass butterflies over the K
 // row bits; tiles of a macro tile are independent (they only share the workgroup).
 //
-// Every thread keeps 16 vectors in registers. A pass is ceil(K/4) ROUNDS; round r butterflies
-// row bits [4r, min(4r+4,K)) entirely in registers, and between rounds the macro tile is
-// exchanged through LDS. For each round the 12-LU "logical bits" (row bits 0..K-1, then tile
-// bits K..K+LT-1) are split into 4 register-index bits and 8-LU thread bits.
+// Every thread keeps 2^RB vectors in registers (2^(LOGV-RB) threads). A pass is ceil(K/RB)
+// ROUNDS; round r butterflies row bits [RB*r, min(RB*r+RB, K)) entirely in registers, and between
+// rounds the macro tile is exchanged through LDS. For each round the LOGV-LU "logical bits" (row
+// bits 0..K-1, then tile bits K..K+LT-1) are split into RB register-index bits and the thread bits.
+//
+// Two configurations are built (zmls_internal.h):
+//   small  LOGV=12 RB=4 LU=2 :  64 KiB tile, 256 threads, 2 workgroups/CU,  64-byte row segments
+//   big    LOGV=14 RB=5 LU=4 : 256 KiB tile, 512 threads, 1 workgroup/CU,  256-byte row segments
+// The big one exists because random row gathers from HBM run at 3.2 / 5.2 / 5.7 TB/s for 64 / 128 /
+// 256-byte segments on MI355X (tools/gather_probe.hip); its tile lives in the register file
+// (512 KiB per CU) and goes through LDS in two halves.
 #pragma once
 #include <stdint.h>
 
@@ -23,38 +30,51 @@
 
 namespace zmls {
 
-constexpr int kLogVecs = 12;     // log2(vectors per macro tile)
-constexpr int kThreads = 256;
-constexpr int kMaxPassBits = 10; // K <= 10: at most three rounds, two LDS exchanges
+constexpr int kMaxPassBits = 10;
 constexpr int kVecBytes = 16;
 
+struct TileCfg {
+    int logv;   // log2(vectors per macro tile)
+    int rb;     // log2(vectors per thread)
+    int lu;     // log2(vectors per row segment)
+};
+
+ZHD constexpr int cfg_threads(TileCfg c) { return 1 << (c.logv - c.rb); }
+ZHD constexpr int cfg_logical_bits(TileCfg c) { return c.logv - c.lu; }
+ZHD constexpr int cfg_thread_logical_bits(TileCfg c) { return c.logv - c.lu - c.rb; }
+// LDS holds at most 2^13 vectors (128 KiB) at a time; bigger tiles are exchanged in phases,
+// one group of channel vectors per phase (channels never mix, so each group is self-contained)
+ZHD constexpr int cfg_log2_phases(TileCfg c) { return c.logv > 13 ? c.logv - 13 : 0; }
+
 struct RoundGeo {
-    int regbit[4];  // logical bit carried by bit j of the register index
+    int regbit[5];  // logical bit carried by bit j of the register index
     int nbf;        // the first nbf of them are butterflied in this round
-    int thrbit[10]; // logical bit carried by bit q of the thread's logical id (tid >> LU)
+    int thrbit[12]; // logical bit carried by bit q of the thread's logical id (tid >> LU)
     int nthr;
 };
 
-ZHD constexpr int num_rounds(int K) { return (K + 3) / 4; }
-ZHD constexpr int log2_tiles(int K, int LU) { return kLogVecs - LU - K; }
+ZHD constexpr int num_rounds(int K, TileCfg c) { return (K + c.rb - 1) / c.rb; }
+ZHD constexpr int log2_tiles(int K, TileCfg c) { return c.logv - c.lu - K; }
 
 // first_pass: the pass works on bit offset 0, its tiles are contiguous runs of rows, and the
 // lanes should walk rows first. Otherwise adjacent TILES are adjacent in memory (they differ
 // in a row bit below the pass's offset), so lanes walk tiles first.
-ZHD constexpr RoundGeo make_round(int K, int LU, bool first_pass, int r)
+ZHD constexpr RoundGeo make_round(int K, TileCfg c, bool first_pass, int r)
 {
-    const int NB = kLogVecs - LU;
+    const int NB = cfg_logical_bits(c);
     RoundGeo g{};
     bool used[16] = {false, false, false, false, false, false, false, false,
                      false, false, false, false, false, false, false, false};
     int n = 0;
-    const int lo = 4 * r;
-    const int hi = (4 * r + 4 < K) ? 4 * r + 4 : K;
+    const int lo = c.rb * r;
+    const int hi = (c.rb * r + c.rb < K) ? c.rb * r + c.rb : K;
     for (int q = lo; q < hi; ++q) { g.regbit[n++] = q; used[q] = true; }
     g.nbf = n;
-    for (int q = K - 1; q >= 0 && n < 4; --q)
+    // fill the register index with bits that are not butterflied now: highest rows first
+    // (low rows stay on the lanes, where they keep global accesses contiguous), then tiles
+    for (int q = K - 1; q >= 0 && n < c.rb; --q)
         if (!used[q]) { g.regbit[n++] = q; used[q] = true; }
-    for (int q = NB - 1; q >= K && n < 4; --q)
+    for (int q = NB - 1; q >= K && n < c.rb; --q)
         if (!used[q]) { g.regbit[n++] = q; used[q] = true; }
     int m = 0;
     if (first_pass) {
@@ -74,23 +94,26 @@ ZHD constexpr uint32_t logical_of_thread(const RoundGeo &g, uint32_t tlog)
     for (int q = 0; q < g.nthr; ++q) l |= ((tlog >> q) & 1u) << g.thrbit[q];
     return l;
 }
-ZHD constexpr uint32_t logical_of_reg(const RoundGeo &g, uint32_t reg)
+ZHD constexpr uint32_t logical_of_reg(const RoundGeo &g, uint32_t reg, int rb)
 {
     uint32_t l = 0;
-    for (int j = 0; j < 4; ++j) l |= ((reg >> j) & 1u) << g.regbit[j];
+    for (int j = 0; j < rb; ++j) l |= ((reg >> j) & 1u) << g.regbit[j];
     return l;
 }
 
-// LDS slot (in 16-byte units) of vector u of logical element l. The two padding terms keep
-// the strided round-to-round exchanges off a single bank group (tools/lds_conflicts.cpp).
-ZHD constexpr uint32_t lds_slot(uint32_t l, uint32_t u, int LU)
+// LDS slot (in 16-byte units) of vector `up` (index within the phase's group of 2^lup vectors)
+// of logical element l. Row segments of 64 bytes get two padding terms that keep the strided
+// round-to-round exchanges off a single bank group; 128-byte segments need none
+// (tools/lds_conflicts.cpp).
+ZHD constexpr uint32_t lds_slot(uint32_t l, uint32_t up, int lup)
 {
-    return (l << LU) + u + (((l >> 4) + (l >> 8)) << 2);
+    return (l << lup) + up + (lup <= 2 ? (((l >> 4) + (l >> 8)) << 2) : 0u);
 }
-ZHD constexpr uint32_t lds_slots_total(int LU)
+ZHD constexpr uint32_t lds_slots_total(TileCfg c)
 {
-    const uint32_t last = (1u << (kLogVecs - LU)) - 1u;
-    return lds_slot(last, (1u << LU) - 1u, LU) + 1u;
+    const int lup = c.lu - cfg_log2_phases(c);
+    const uint32_t last = (1u << cfg_logical_bits(c)) - 1u;
+    return lds_slot(last, (1u << lup) - 1u, lup) + 1u;
 }
 
 // Global row d (index into the 2^N-point transform) of row i of tile `tile` for a pass that

@@ -54,19 +54,22 @@ __global__ void __launch_bounds__(256) lfsr_tables_kernel(int N, uint32_t G, uin
     }
 }
 
-__global__ void __launch_bounds__(256) scatter_perm_kernel(int N, int K, int LU, int b, const uint32_t *__restrict__ nat,
+// M in the order the last pass's threads want it: entry ((macro*2^RB + reg) << TLB) + tlog is the
+// response row of the element thread-logical-id tlog holds in register reg (TLB = thread logical bits)
+__global__ void __launch_bounds__(256) scatter_perm_kernel(int N, int K, TileCfg cfg, int b, const uint32_t *__restrict__ nat,
                                                            uint32_t *__restrict__ perm)
 {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (1ull << N)) return;
-    const int LT = log2_tiles(K, LU);
-    const RoundGeo g = make_round(K, LU, false, num_rounds(K) - 1);
-    const uint32_t per_macro_bits = kLogVecs - LU;
+    const int LT = log2_tiles(K, cfg);
+    const RoundGeo g = make_round(K, cfg, false, num_rounds(K, cfg) - 1);
+    const uint32_t per_macro_bits = cfg_logical_bits(cfg);
+    const uint32_t tlb = cfg_thread_logical_bits(cfg);
     const uint64_t macro = idx >> per_macro_bits;
     const uint32_t within = (uint32_t)(idx & ((1u << per_macro_bits) - 1u));
-    const uint32_t reg = within >> (8 - LU);
-    const uint32_t tlog = within & ((1u << (8 - LU)) - 1u);
-    const uint32_t l = logical_of_thread(g, tlog) | logical_of_reg(g, reg);
+    const uint32_t reg = within >> tlb;
+    const uint32_t tlog = within & ((1u << tlb) - 1u);
+    const uint32_t l = logical_of_thread(g, tlog) | logical_of_reg(g, reg, cfg.rb);
     perm[idx] = nat[row_of_logical(macro, l, b, K, LT)];
 }
 
@@ -175,10 +178,10 @@ int launch_lfsr_tables(int N, uint32_t G, uint32_t s0, const JumpTables *d_jt, u
     return ZMLS_OK;
 }
 
-int launch_scatter_perm(int N, int K, int LU, int b, const uint32_t *d_scatter_nat, uint32_t *d_scatter_perm, hipStream_t st)
+int launch_scatter_perm(int N, int K, TileCfg cfg, int b, const uint32_t *d_scatter_nat, uint32_t *d_scatter_perm, hipStream_t st)
 {
     const uint64_t n = 1ull << N;
-    hipLaunchKernelGGL(scatter_perm_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, N, K, LU, b, d_scatter_nat, d_scatter_perm);
+    hipLaunchKernelGGL(scatter_perm_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, N, K, cfg, b, d_scatter_nat, d_scatter_perm);
     ZHIP(hipGetLastError());
     return ZMLS_OK;
 }

@@ -106,27 +106,31 @@ int zmls_host_lfsr_state(int N, const int32_t *taps, int ntaps, uint64_t steps, 
 }
 
 // Walk the geometry exactly as the kernels do and check it is a consistent tiling.
-int zmls_host_geometry_selfcheck(int K, int LU, int first_pass)
+int zmls_host_geometry_selfcheck(int K, int cfg_id, int first_pass)
 {
-    if (K < 1 || K > kMaxPassBits || LU < 0 || kLogVecs - LU - K < 0) { set_error("bad geometry arguments"); return ZMLS_E_ARG; }
-    const int NB = kLogVecs - LU;
+    if (cfg_id < 0 || cfg_id >= CFG_COUNT) { set_error("bad tile configuration"); return ZMLS_E_ARG; }
+    const TileCfg C = kCfg[cfg_id];
+    if (K < 1 || K > kMaxPassBits || log2_tiles(K, C) < 0) { set_error("bad geometry arguments"); return ZMLS_E_ARG; }
+    const int NB = cfg_logical_bits(C);
     const uint32_t n_log = 1u << NB;
-    const int U = 1 << LU;
-    const uint32_t slots = lds_slots_total(LU);
+    const int LUP = C.lu - cfg_log2_phases(C);
+    const int U = 1 << LUP;
+    const uint32_t slots = lds_slots_total(C);
+    if ((size_t)slots * kVecBytes > 160 * 1024) { set_error("LDS image larger than a CU's 160 KiB"); return -99; }
     std::vector<int> slot_owner(slots, -1);
     for (uint32_t l = 0; l < n_log; ++l)
         for (int u = 0; u < U; ++u) {
-            const uint32_t s = lds_slot(l, (uint32_t)u, LU);
+            const uint32_t s = lds_slot(l, (uint32_t)u, LUP);
             if (s >= slots || slot_owner[s] != -1) { set_error("LDS slot clash at l=%u u=%d", l, u); return -100; }
             slot_owner[s] = (int)l;
         }
-    for (int r = 0; r < num_rounds(K); ++r) {
-        const RoundGeo g = make_round(K, LU, first_pass != 0, r);
-        if (g.nthr != NB - 4) { set_error("round %d: %d thread bits, expected %d", r, g.nthr, NB - 4); return -101; }
+    for (int r = 0; r < num_rounds(K, C); ++r) {
+        const RoundGeo g = make_round(K, C, first_pass != 0, r);
+        if (g.nthr != NB - C.rb) { set_error("round %d: %d thread bits, expected %d", r, g.nthr, NB - C.rb); return -101; }
         std::vector<int> seen(n_log, 0);
-        for (uint32_t tlog = 0; tlog < (uint32_t)(kThreads >> LU); ++tlog)
-            for (uint32_t reg = 0; reg < 16; ++reg) {
-                const uint32_t l = logical_of_thread(g, tlog) | logical_of_reg(g, reg);
+        for (uint32_t tlog = 0; tlog < (uint32_t)(cfg_threads(C) >> C.lu); ++tlog)
+            for (uint32_t reg = 0; reg < (1u << C.rb); ++reg) {
+                const uint32_t l = logical_of_thread(g, tlog) | logical_of_reg(g, reg, C.rb);
                 if (l >= n_log) { set_error("round %d: logical index out of range", r); return -102; }
                 seen[l]++;
             }
@@ -134,10 +138,10 @@ int zmls_host_geometry_selfcheck(int K, int LU, int first_pass)
             if (seen[l] != 1) { set_error("round %d: element %u held %d times", r, l, seen[l]); return -103; }
         // butterflied bits must be exactly rows [4r, min(4r+4,K)) and sit in the low register bits
         for (int j = 0; j < g.nbf; ++j)
-            if (g.regbit[j] != 4 * r + j) { set_error("round %d: register bit %d carries logical bit %d", r, j, g.regbit[j]); return -104; }
+            if (g.regbit[j] != C.rb * r + j) { set_error("round %d: register bit %d carries logical bit %d", r, j, g.regbit[j]); return -104; }
     }
     // rows of a pass at bit offset b: every row of the 2^(K+LT+b')-row neighbourhood exactly once
-    const int LT = kLogVecs - LU - K;
+    const int LT = log2_tiles(K, C);
     for (int b = 0; b <= (first_pass ? 0 : 6); ++b) {
         const uint64_t n_macro = 4;   // a few macro tiles are enough to see overlaps
         const uint64_t span = (n_macro << (LT + K)) + ((uint64_t)1 << (b + K + 8));

@@ -9,8 +9,12 @@
 namespace zmls {
 
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
-constexpr int kLU = 2;                 // 4 vectors = 64 bytes per row segment of a slab
 constexpr int kSynthTaps = 16;
+
+// tile configurations (geometry.h). CFG_SMALL is the general one (any channel count, any strides,
+// single-pass orders); CFG_BIG is the streaming one for wide, vector-aligned channel blocks.
+enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_COUNT = 2 };
+constexpr TileCfg kCfg[CFG_COUNT] = {{12, 4, 2}, {14, 5, 4}};
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
@@ -60,7 +64,7 @@ struct PassArgs {
     uint32_t n_macro;         // macro tiles per slab (single: 1)
     uint32_t n_slab_groups;   // slabs (single: groups of 2^LT slabs) in this launch
     uint32_t swz_group;       // XCD swizzle group size (0 = identity)
-    void *work;               // [slab][2^N rows][4 vectors]
+    void *work;               // [slab][2^N rows][2^LU vectors]
     // gather-in
     const void *x;
     int in_dtype;
@@ -76,13 +80,13 @@ struct PassArgs {
     const uint32_t *scatter;  // last pass's thread order (single: natural order)
 };
 
-int launch_pass_f64(int K, int inm, int outm, const PassArgs &a, hipStream_t st);
-int launch_pass_f32(int K, int inm, int outm, const PassArgs &a, hipStream_t st);
+int launch_pass_f64(int cfg, int K, int inm, int outm, const PassArgs &a, hipStream_t st);
+int launch_pass_f32(int cfg, int K, int inm, int outm, const PassArgs &a, hipStream_t st);
 
 // ---- plan-time kernels (lfsr.hip)
 int launch_lfsr_tables(int N, uint32_t G, uint32_t s0, const JumpTables *d_jt, uint32_t *d_bits,
                        uint64_t n_words, uint32_t *d_gather, uint32_t *d_scatter_nat, hipStream_t st);
-int launch_scatter_perm(int N, int K, int LU, int b, const uint32_t *d_scatter_nat, uint32_t *d_scatter_perm,
+int launch_scatter_perm(int N, int K, TileCfg cfg, int b, const uint32_t *d_scatter_nat, uint32_t *d_scatter_perm,
                         hipStream_t st);
 int launch_sequence_expand(const uint32_t *d_bits, int64_t L, void *d_out, int dtype, int64_t repeats,
                            int64_t stride, hipStream_t st);
@@ -112,8 +116,9 @@ struct zmls_plan {
     uint64_t n_words;
     uint32_t *d_gather;           // Q[d], 2^N
     uint32_t *d_scatter_nat;      // M[d], 2^N
-    uint32_t *d_scatter_perm;     // M in the last pass's thread order (multi-pass plans)
+    uint32_t *d_scatter_perm[zmls::CFG_COUNT];   // M in the last pass's thread order, per tile configuration (multi-pass plans)
     zmls::JumpTables *d_jt;
     void *d_work;
     size_t work_bytes;
+    int force_cfg;                // -1: choose per call; else a tile configuration (tests, tuning)
 };

@@ -79,7 +79,12 @@ class Plan:
         L.check(L.lib().zmls_plan_info(self._h, buf))
         v = list(buf)
         return {"N": v[0], "L": v[1], "dtype": v[2], "device": v[3], "passes": v[4],
-                "pass_bits": [b for b in v[5:8] if b], "workspace_bytes": v[8], "channels_per_slab": v[9]}
+                "pass_bits": [b for b in v[5:8] if b], "workspace_bytes": v[8], "channels_per_slab": v[9],
+                "channels_per_slab_big": v[10]}
+
+    def force_tile(self, cfg):
+        """-1 auto, 0 small tile, 1 big tile (tests / tuning)"""
+        L.check(L.lib().zmls_plan_force_tile(self._h, int(cfg)))
 
     def reserve(self, n_ch):
         L.check(L.lib().zmls_plan_reserve(self._h, int(n_ch)))
@@ -140,6 +145,14 @@ class Plan:
                        out_row_stride, out_ch_stride, stream=None):
         L.check(L.lib().zmls_impulse_device(self._h, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride,
                                             d_h, out_row_stride, out_ch_stride, stream))
+
+    def impulse_device_timed(self, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h,
+                             out_row_stride, out_ch_stride, stream=None):
+        """Same launches with HIP events around every pass kernel; returns [ms per pass]."""
+        ms = (ctypes.c_float * 4)()
+        L.check(L.lib().zmls_impulse_device_timed(self._h, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride,
+                                                  d_h, out_row_stride, out_ch_stride, stream, ms))
+        return list(ms)[:self.info()["passes"]]
 
     def synth_device(self, d_x, dtype_code, repeats, n_ch, row_stride, ch_stride, seed=0x5A17,
                      sigma=1e-3, ch_first=0, stream=None):
