@@ -122,7 +122,7 @@ def test_multichannel_layouts(N, C):
 def test_device_entry_point_chunks_channels_with_small_workspace():
     """zmls_impulse_device never allocates: with a workspace of one slab it must loop over the
     channel slabs itself and still give the same answer; with none it must refuse."""
-    N, C, R = 13, 24, 3
+    N, C, R = 13, 72, 3
     taps = TAPS[N][0]
     L = (1 << N) - 1
     rng = np.random.default_rng(7)
@@ -130,16 +130,21 @@ def test_device_entry_point_chunks_channels_with_small_workspace():
     want = plan(N, taps).impulse_host(x)
     from zignal_amd.device import Plan
     p = Plan(N, taps, device=0)
+    p.force_tile(0)                               # small tile: 8 float64 channels per slab
     dx = DeviceBuffer(x.nbytes).upload(x)
     dh = DeviceBuffer(L * C * 8)
     with pytest.raises(_lib.ZmlsError) as ei:
         p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)
     assert ei.value.code == _lib.E_WORKSPACE
-    p.reserve(8)                                  # one slab of 8 float64 channels
-    assert p.info()["workspace_bytes"] == (1 << N) * 64
-    p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)
+    p.reserve(8)                                  # room for one slab of the wider (big) tile = 4 small slabs
+    assert p.info()["workspace_bytes"] == (1 << N) * 256
+    p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)     # 9 slabs -> 3 chunks
     got = dh.download((L, C), np.float64)
-    assert np.array_equal(got, want)              # same kernels, same order of operations
+    assert rel_err(got, want) <= 1e-14
+    p.force_tile(1)                               # big tile: 32 channels per slab -> 3 chunks of one slab
+    dh.fill(0)
+    p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)
+    assert rel_err(dh.download((L, C), np.float64), want) <= 1e-14
     p.close()
 
 
