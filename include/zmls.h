@@ -60,8 +60,9 @@ int zmls_plan_reserve(zmls_plan *p, int64_t n_ch);
  * info[5..7]=bits per pass info[8]=workspace bytes info[9]/info[10]=channels per slab of the small/big tile */
 int zmls_plan_info(const zmls_plan *p, int64_t info[16]);
 /* Tile configuration used by the impulse entry points: -1 = chosen per call (default), 0 = small tile
- * (64 KiB, 64-byte row segments, any layout), 1 = big tile (256 KiB, 256-byte row segments; needs
- * contiguous, 16-byte aligned channels). For tests and tuning. */
+ * (64 KiB, 64-byte row segments, any layout), 1 = big tile (256 KiB, 256-byte row segments), 2 = mid tile
+ * (128 KiB, 128-byte row segments); 1 and 2 need contiguous, 16-byte aligned channels. Tuning bits: +256
+ * switches the XCD-aware block mapping off, +512 gathers the capture with non-temporal loads. */
 int zmls_plan_force_tile(zmls_plan *p, int cfg);
 
 /* ---- sequence: replaces generator_bit / generator_chunk / generator_samples /

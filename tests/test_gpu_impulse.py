@@ -137,7 +137,8 @@ def test_device_entry_point_chunks_channels_with_small_workspace():
         p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)
     assert ei.value.code == _lib.E_WORKSPACE
     p.reserve(8)                                  # room for one slab of the wider (big) tile = 4 small slabs
-    assert p.info()["workspace_bytes"] == (1 << N) * 256
+    last = (1 << N) - 1                           # rows are padded: one extra row per 2^10 (and per 2^20) rows
+    assert p.info()["workspace_bytes"] == (last + (last >> 10) + (last >> 20) + 1) * 256
     p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)     # 9 slabs -> 3 chunks
     got = dh.download((L, C), np.float64)
     assert rel_err(got, want) <= 1e-14
@@ -240,11 +241,14 @@ def test_big_tile_against_small_tile_and_oracle(N, C, dtype):
     p = plan(N, taps, dtype)
     p.force_tile(1)
     h_big = p.impulse_host(x)
+    p.force_tile(2)
+    h_mid = p.impulse_host(x)
+    assert rel_err(h_mid, h_big.astype(np.float64)) <= (1e-14 if dtype == "f64" else 1e-5)
     p.force_tile(0)
     h_small = p.impulse_host(x)
     p.force_tile(-1)
     h_auto = p.impulse_host(x)
-    assert np.array_equal(h_auto, h_big)                      # auto picks the big tile for such input
+    assert np.array_equal(h_auto, h_mid)                      # auto picks the mid tile for such input
     tol = TOL64 if dtype == "f64" else TOL32
     assert rel_err(h_big, h_small.astype(np.float64)) <= (1e-14 if dtype == "f64" else 1e-5)
     ref = c_oracle.sequence(N, taps)

@@ -54,8 +54,10 @@ def test_pass_split(lib):
 
 @pytest.mark.parametrize("first", [0, 1])
 @pytest.mark.parametrize("K", range(1, 11))
-@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("cfg", [0, 1, 2])
 def test_tile_geometry_is_a_tiling(lib, cfg, K, first):
+    if cfg == 2 and K == 10 and False:
+        pytest.skip("")
     assert lib.zmls_host_geometry_selfcheck(K, cfg, first) == 0, _lib.last_error()
 
 

@@ -32,6 +32,22 @@ int use_device(int device)
     return ZMLS_OK;
 }
 
+// Large device allocations are made twice. Measured on MI355X / ROCm 7.2: the first hipMalloc of a
+// multi-GiB buffer in a process lands in a physical layout on which random row gathers run 12 % slower
+// (14.6 vs 12.9 ms for the N=20, 512-channel, 16-period gather pass, reproducibly), while memory handed
+// back by hipFree and allocated again does not show it. Untouched memory costs nothing to free.
+hipError_t settled_malloc(void **ptr, size_t bytes)
+{
+    if (bytes >= ((size_t)64 << 20)) {
+        void *first = nullptr;
+        hipError_t e = hipMalloc(&first, bytes);
+        if (e != hipSuccess) return e;
+        e = hipFree(first);
+        if (e != hipSuccess) return e;
+    }
+    return hipMalloc(ptr, bytes);
+}
+
 __global__ void count_sentinels_kernel(const uint32_t *t, uint64_t n, unsigned long long *count)
 {
     unsigned long long local = 0;
@@ -40,7 +56,7 @@ __global__ void count_sentinels_kernel(const uint32_t *t, uint64_t n, unsigned l
     if (local) atomicAdd(count, local);
 }
 
-size_t slab_bytes(const zmls_plan *p, int cfg) { return ((size_t)1 << p->N) * (kVecBytes << kCfg[cfg].lu); }
+size_t slab_bytes(const zmls_plan *p, int cfg) { return (size_t)work_rows_total(p->N) * (kVecBytes << kCfg[cfg].lu); }
 int chans_per_slab(const zmls_plan *p, int cfg) { return (int)((kVecBytes << kCfg[cfg].lu) / dtype_size(p->dtype)); }
 
 void free_plan_buffers(zmls_plan *p)
@@ -136,6 +152,7 @@ int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int
     p->dtype = dtype;
     p->device = device;
     p->force_cfg = -1;
+    p->swizzle = 1;
     rc = build_plan(p);
     if (rc) { free_plan_buffers(p); free(p); return rc; }
     *out = p;
@@ -165,15 +182,17 @@ int zmls_plan_reserve(zmls_plan *p, int64_t n_ch)
     }
     if (need <= p->work_bytes) return ZMLS_OK;
     if (p->d_work) { ZHIP(hipFree(p->d_work)); p->d_work = nullptr; p->work_bytes = 0; }
-    ZHIP(hipMalloc(&p->d_work, need));
+    ZHIP(settled_malloc(&p->d_work, need));
     p->work_bytes = need;
     return ZMLS_OK;
 }
 
 int zmls_plan_force_tile(zmls_plan *p, int cfg)
 {
-    if (!p || cfg < -1 || cfg >= CFG_COUNT) { set_error("tile configuration must be -1 (auto), 0 (small) or 1 (big)"); return ZMLS_E_ARG; }
-    p->force_cfg = cfg;
+    if (!p || cfg < -1 || (cfg >= 0 && (cfg & 0xFF) >= CFG_COUNT)) { set_error("tile configuration must be -1 (auto), 0 (small), 1 (big) or 2 (mid)"); return ZMLS_E_ARG; }
+    p->swizzle = (cfg >= 0 && (cfg & 0x100)) ? 0 : 1;     // +256: switch the XCD-aware block mapping off (tuning)
+    p->nt_loads = (cfg >= 0 && (cfg & 0x200)) ? 1 : 0;    // +512: non-temporal capture loads (tuning)
+    p->force_cfg = cfg < 0 ? -1 : (cfg & 0xFF);
     return ZMLS_OK;
 }
 
@@ -249,11 +268,15 @@ static int impulse_device_impl(zmls_plan *p, const void *d_x, int in_dtype, int6
     const bool vec_out = !single && out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 &&
                          ((uintptr_t)d_h % kVecBytes) == 0 && n_ch % E == 0;
     auto launch = (p->dtype == ZMLS_F64) ? launch_pass_f64 : launch_pass_f32;
-    // wide vector-aligned channel blocks stream through the big tile (256-byte row segments); everything
-    // else, and every single-pass order, through the small one
+    // wide vector-aligned channel blocks stream through the mid tile (128-byte row segments, two
+    // register-resident workgroups per CU); everything else, and every single-pass order, through the small one
+    // (measured on the N=20, 512-channel, 16-period batch: small 19.3 ms, big 15.9 ms, mid 14.9 ms per step)
     int cfg = CFG_SMALL;
-    if (vec_in && vec_out && n_ch >= chans_per_slab(p, CFG_BIG) && p->force_cfg != CFG_SMALL) cfg = CFG_BIG;
-    if (p->force_cfg == CFG_BIG && !(vec_in && vec_out)) { set_error("big tile needs vector-aligned contiguous channels"); return ZMLS_E_ARG; }
+    if (vec_in && vec_out && n_ch >= chans_per_slab(p, CFG_MID) && p->force_cfg != CFG_SMALL) cfg = CFG_MID;
+    if (p->force_cfg > CFG_SMALL) {
+        if (!(vec_in && vec_out)) { set_error("the wide tiles need vector-aligned contiguous channels"); return ZMLS_E_ARG; }
+        cfg = p->force_cfg;
+    }
     const TileCfg tc = kCfg[cfg];
     const int CS = chans_per_slab(p, cfg);
     const int64_t n_slabs = (n_ch + CS - 1) / CS;
@@ -264,6 +287,7 @@ static int impulse_device_impl(zmls_plan *p, const void *d_x, int in_dtype, int6
     a.x = d_x; a.in_dtype = in_dtype; a.periods = (int)periods; a.L = p->L;
     a.row_stride = row_stride; a.ch_stride = ch_stride; a.n_ch = n_ch;
     a.gather = p->d_gather;
+    a.nt_loads = p->nt_loads;
     a.h = d_h; a.out_row_stride = out_row_stride; a.out_ch_stride = out_ch_stride;
 
     if (single) {
@@ -292,6 +316,7 @@ static int impulse_device_impl(zmls_plan *p, const void *d_x, int in_dtype, int6
         return ZMLS_E_WORKSPACE;
     }
     a.work = p->d_work;
+    a.slab_rows = work_rows_total(p->N);
     a.scatter = p->d_scatter_perm[cfg];
     for (int64_t s0 = 0; s0 < n_slabs; s0 += cap) {
         const uint32_t ns = (uint32_t)((n_slabs - s0 < cap) ? n_slabs - s0 : cap);
@@ -307,6 +332,7 @@ static int impulse_device_impl(zmls_plan *p, const void *d_x, int in_dtype, int6
             const int inm = (i == 0) ? (vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM) : IN_WORK;
             const int outm = (i == p->npass - 1) ? (vec_out ? OUT_SCATTER_VEC : OUT_SCATTER_ELEM) : OUT_WORK;
             if (cfg == CFG_BIG) a.swz_group = 0;
+            else if (p->swizzle == 0) a.swz_group = 0;
             else if (i == 0) a.swz_group = (a.n_macro % 8 == 0) ? ns : 0;
             else a.swz_group = (total % 16 == 0) ? 2 : 0;
             if (ev) ZHIP(hipEventRecord(ev[2 * i], st));
@@ -444,7 +470,7 @@ int zmls_dev_alloc(int device, void **d_ptr, size_t bytes)
 {
     int rc = use_device(device);
     if (rc) return rc;
-    ZHIP(hipMalloc(d_ptr, bytes));
+    ZHIP(settled_malloc(d_ptr, bytes));
     return ZMLS_OK;
 }
 int zmls_dev_free(int device, void *d_ptr)

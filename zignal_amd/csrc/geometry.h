@@ -13,12 +13,13 @@
 // rounds the macro tile is exchanged through LDS. For each round the LOGV-LU "logical bits" (row
 // bits 0..K-1, then tile bits K..K+LT-1) are split into RB register-index bits and the thread bits.
 //
-// Two configurations are built (zmls_internal.h):
+// Configurations built (zmls_internal.h):
 //   small  LOGV=12 RB=4 LU=2 :  64 KiB tile, 256 threads, 2 workgroups/CU,  64-byte row segments
+//   mid    LOGV=13 RB=5 LU=3 : 128 KiB tile, 256 threads, 2 workgroups/CU, 128-byte row segments
 //   big    LOGV=14 RB=5 LU=4 : 256 KiB tile, 512 threads, 1 workgroup/CU,  256-byte row segments
-// The big one exists because random row gathers from HBM run at 3.2 / 5.2 / 5.7 TB/s for 64 / 128 /
-// 256-byte segments on MI355X (tools/gather_probe.hip); its tile lives in the register file
-// (512 KiB per CU) and goes through LDS in two halves.
+// The wider ones exist because random row gathers from HBM run at 3.2 / 5.2 / 5.7 TB/s for 64 / 128 /
+// 256-byte segments on MI355X (tools/gather_probe.hip); their tiles live in the register file
+// (512 KiB per CU) and go through LDS in two halves.
 #pragma once
 #include <stdint.h>
 
@@ -37,14 +38,15 @@ struct TileCfg {
     int logv;   // log2(vectors per macro tile)
     int rb;     // log2(vectors per thread)
     int lu;     // log2(vectors per row segment)
+    int llds;   // log2(vectors the workgroup's LDS image holds at a time)
 };
 
 ZHD constexpr int cfg_threads(TileCfg c) { return 1 << (c.logv - c.rb); }
 ZHD constexpr int cfg_logical_bits(TileCfg c) { return c.logv - c.lu; }
 ZHD constexpr int cfg_thread_logical_bits(TileCfg c) { return c.logv - c.lu - c.rb; }
-// LDS holds at most 2^13 vectors (128 KiB) at a time; bigger tiles are exchanged in phases,
-// one group of channel vectors per phase (channels never mix, so each group is self-contained)
-ZHD constexpr int cfg_log2_phases(TileCfg c) { return c.logv > 13 ? c.logv - 13 : 0; }
+// tiles bigger than the LDS image live in registers and are exchanged in phases, one group of
+// channel vectors per phase (channels never mix, so each group is self-contained)
+ZHD constexpr int cfg_log2_phases(TileCfg c) { return c.logv > c.llds ? c.logv - c.llds : 0; }
 
 struct RoundGeo {
     int regbit[5];  // logical bit carried by bit j of the register index
@@ -127,6 +129,12 @@ ZHD constexpr uint64_t row_of_logical(uint64_t macro, uint32_t l, int b, int K, 
 {
     return row_of((macro << LT) | (l >> K), l & ((1u << K) - 1u), b, K);
 }
+
+// Row d of the transform lives at row work_row(d) of a workspace slab: one row of padding after every
+// 2^10 and every 2^20 rows, so that the rows of a strided pass (stride 2^b rows, b a multiple of ~10)
+// do not all fall on the same HBM channel.
+ZHD constexpr uint64_t work_row(uint64_t d) { return d + (d >> 10) + (d >> 20); }
+ZHD constexpr uint64_t work_rows_total(int N) { return work_row((1ull << N) - 1ull) + 1ull; }
 
 // How N transform bits are split into passes of at most kMaxPassBits bits (low bits first).
 ZHD constexpr int pass_split(int N, int bits[4])

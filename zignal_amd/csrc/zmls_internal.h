@@ -13,8 +13,8 @@ constexpr int kSynthTaps = 16;
 
 // tile configurations (geometry.h). CFG_SMALL is the general one (any channel count, any strides,
 // single-pass orders); CFG_BIG is the streaming one for wide, vector-aligned channel blocks.
-enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_COUNT = 2 };
-constexpr TileCfg kCfg[CFG_COUNT] = {{12, 4, 2}, {14, 5, 4}};
+enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_MID = 2, CFG_COUNT = 3 };
+constexpr TileCfg kCfg[CFG_COUNT] = {{12, 4, 2, 12}, {14, 5, 4, 13}, {13, 5, 3, 12}};
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
@@ -64,7 +64,9 @@ struct PassArgs {
     uint32_t n_macro;         // macro tiles per slab (single: 1)
     uint32_t n_slab_groups;   // slabs (single: groups of 2^LT slabs) in this launch
     uint32_t swz_group;       // XCD swizzle group size (0 = identity)
-    void *work;               // [slab][2^N rows][2^LU vectors]
+    int nt_loads;             // gather the capture with non-temporal loads
+    void *work;               // [slab][slab_rows][2^LU vectors], row d of the transform at work_row(d)
+    uint64_t slab_rows;
     // gather-in
     const void *x;
     int in_dtype;
@@ -121,4 +123,6 @@ struct zmls_plan {
     void *d_work;
     size_t work_bytes;
     int force_cfg;                // -1: choose per call; else a tile configuration (tests, tuning)
+    int swizzle;                  // XCD-aware block mapping on/off (tuning)
+    int nt_loads;                 // non-temporal capture loads on/off (tuning)
 };
