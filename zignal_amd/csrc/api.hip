@@ -192,6 +192,7 @@ int zmls_plan_force_tile(zmls_plan *p, int cfg)
     if (!p || cfg < -1 || (cfg >= 0 && (cfg & 0xFF) >= CFG_COUNT)) { set_error("tile configuration must be -1 (auto), 0 (small), 1 (big) or 2 (mid)"); return ZMLS_E_ARG; }
     p->swizzle = (cfg >= 0 && (cfg & 0x100)) ? 0 : 1;     // +256: switch the XCD-aware block mapping off (tuning)
     p->nt_loads = (cfg >= 0 && (cfg & 0x200)) ? 1 : 0;    // +512: non-temporal capture loads (tuning)
+    p->work_layout = (cfg >= 0 && (cfg & 0x400)) ? 1 : 0; // +1024: row-major workspace (tuning)
     p->force_cfg = cfg < 0 ? -1 : (cfg & 0xFF);
     return ZMLS_OK;
 }
@@ -316,12 +317,15 @@ static int impulse_device_impl(zmls_plan *p, const void *d_x, int in_dtype, int6
         return ZMLS_E_WORKSPACE;
     }
     a.work = p->d_work;
-    a.slab_rows = work_rows_total(p->N);
     a.scatter = p->d_scatter_perm[cfg];
     for (int64_t s0 = 0; s0 < n_slabs; s0 += cap) {
         const uint32_t ns = (uint32_t)((n_slabs - s0 < cap) ? n_slabs - s0 : cap);
         a.ch_first = s0 * CS;
         a.n_slab_groups = ns;
+        const uint64_t U = 1ull << tc.lu;
+        a.slab_fastest = p->work_layout;
+        a.work_slab_stride = p->work_layout ? U : work_rows_total(p->N) * U;
+        a.work_row_stride = p->work_layout ? (uint64_t)ns * U : U;
         int b = 0;
         for (int i = 0; i < p->npass; ++i) {
             const int K = p->bits[i];
@@ -333,7 +337,7 @@ static int impulse_device_impl(zmls_plan *p, const void *d_x, int in_dtype, int6
             const int outm = (i == p->npass - 1) ? (vec_out ? OUT_SCATTER_VEC : OUT_SCATTER_ELEM) : OUT_WORK;
             if (cfg == CFG_BIG) a.swz_group = 0;
             else if (p->swizzle == 0) a.swz_group = 0;
-            else if (i == 0) a.swz_group = (a.n_macro % 8 == 0) ? ns : 0;
+            else if (i == 0 || p->work_layout) a.swz_group = (a.n_macro % 8 == 0) ? ns : 0;
             else a.swz_group = (total % 16 == 0) ? 2 : 0;
             if (ev) ZHIP(hipEventRecord(ev[2 * i], st));
             rc = launch(cfg, K, inm, outm, a, st);
