@@ -34,7 +34,8 @@ typedef enum {
     ZMLS_E_HIP = -2,        /* a HIP runtime call failed */
     ZMLS_E_NODEVICE = -3,   /* no usable GPU: there is NO CPU fallback */
     ZMLS_E_WORKSPACE = -4,  /* plan workspace too small for even one channel slab */
-    ZMLS_E_UNSUPPORTED = -5
+    ZMLS_E_UNSUPPORTED = -5,
+    ZMLS_E_COMM = -6        /* librccl could not be loaded, or an RCCL call failed */
 } zmls_status;
 
 typedef enum { ZMLS_F64 = 0, ZMLS_F32 = 1, ZMLS_I16 = 2, ZMLS_I32 = 3 } zmls_dtype;
@@ -103,6 +104,56 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
  * averages float32 in float32), float64 otherwise. */
 int zmls_average_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch,
                       int64_t row_stride, int64_t ch_stride, void *out);
+
+/* ---- several GPUs. Channels are independent (the reference handles one channel per call,
+ * mls.py:338-343), so the normal multi-GPU use is one process per GPU, each calling
+ * zmls_impulse_device on its own channels: no exchange, nothing below is needed.
+ *
+ * The entry points below are for captures whose PERIODS are spread over the GPUs (every rank holds some
+ * of the repeats of every channel). trim_and_avgerage (mls.py:284-306) is a sum over periods then a
+ * division, and xcorr_circular (mls.py:169-256) is linear, so: every rank adds up its own periods, the
+ * partial sums are reduce-scattered over the channel axis with RCCL (rank q receives the complete sums
+ * of channels [q*n_ch/P, (q+1)*n_ch/P)), and rank q divides by the total period count, transforms and
+ * scatters those channels. librccl is loaded on first use. One process per GPU. */
+typedef struct zmls_comm zmls_comm;
+#define ZMLS_COMM_ID_BYTES 128
+/* rank 0 makes the id (ncclGetUniqueId) and hands the bytes to the other ranks by whatever means the
+ * host program has (torch.distributed/gloo broadcast, MPI, a file); every rank then creates its end. */
+int zmls_comm_unique_id(uint8_t *id /* ZMLS_COMM_ID_BYTES */);
+int zmls_comm_create(zmls_comm **out, const uint8_t *id, int rank, int n_ranks, int device);
+int zmls_comm_destroy(zmls_comm *c);
+/* info[0]=rank info[1]=ranks info[2]=device info[3]=chunk channels info[4]=staging bytes */
+int zmls_comm_info(const zmls_comm *c, int64_t info[8]);
+/* Staging for zmls_impulse_period_sharded_device: the exchange handles `chunk_ch` channels of every
+ * rank's share at a time, double-buffered: 2*(P+1)*L*chunk_ch elements of the plan's dtype, plus the
+ * plan's workspace for chunk_ch channels. Allocates; call outside timed regions. */
+int zmls_comm_reserve(zmls_comm *c, zmls_plan *p, int64_t chunk_ch);
+/* ncclReduceScatter(sum) / ncclAllGather on device buffers of ZMLS_F64 / ZMLS_F32, enqueued on hip_stream */
+int zmls_comm_reduce_scatter_device(zmls_comm *c, const void *d_send, void *d_recv, int64_t recv_count, int dtype, void *hip_stream);
+int zmls_comm_all_gather_device(zmls_comm *c, const void *d_send, void *d_recv, int64_t send_count, int dtype, void *hip_stream);
+
+/* the three steps on their own (the fused entry point below chains them; tests use them one by one) */
+/* out[q][j][c'] = sum over periods skip_periods..n_rows/L-1 of x[(period*L + j), q*block_ch_stride + ch_first + c'],
+ * q < n_blocks, j < L, c' < block_ch; element type = the plan's dtype; this is the reduce-scatter send layout. */
+int zmls_period_sum_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int skip_periods,
+                           int64_t row_stride, int64_t ch_stride, int64_t n_blocks, int64_t block_ch_stride,
+                           int64_t ch_first, int64_t block_ch, void *d_out, void *hip_stream);
+/* impulse responses from ONE period of sums (L frames, plan dtype): h = xcorr_circular(s / total_periods) */
+int zmls_impulse_sums_device(zmls_plan *p, const void *d_s, int64_t total_periods, int64_t n_ch,
+                             int64_t row_stride, int64_t ch_stride,
+                             void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
+/* Fused, chunked and overlapped. Collective: every rank of the communicator calls it with the same N, taps,
+ * dtype, n_ch and total_periods.
+ *   d_x           this rank's periods: n_rows = R_local*L frames x n_ch channels (R_local may be 0)
+ *   skip_periods  leading periods of d_x that are not averaged (1 on the rank that holds the period the
+ *                 reference throws away, mls.py:284; else 0)
+ *   total_periods averaged periods over ALL ranks (the divisor)
+ *   d_h           L frames x n_ch/P channels: this rank's channel block [rank*n_ch/P, (rank+1)*n_ch/P)
+ * Enqueues on hip_stream and on the communicator's own stream; never allocates or synchronises. */
+int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d_x, int in_dtype, int64_t n_rows,
+                                       int skip_periods, int64_t total_periods, int64_t n_ch,
+                                       int64_t row_stride, int64_t ch_stride,
+                                       void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
 
 /* ---- synthetic captures for benchmarking/tests (no reference counterpart; the
  * shape follows examples/ex_mls.py:16-28: stimulus through a short filter with a

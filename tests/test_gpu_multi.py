@@ -1,0 +1,140 @@
+"""GPU parity for the period-sharded multi-GPU mode, on the one GPU a test box has:
+the three device steps (period sums in the exchange layout, RCCL reduce-scatter, transform of summed
+periods) one by one with two emulated ranks, and the fused, chunked entry point on a one-rank RCCL
+communicator against zmls_impulse_device and the oracle. Tolerance: 1e-12 x peak (f64), 1e-5 (f32)."""
+import numpy as np
+import pytest
+
+from gpu_common import oracle_ir, plan, rel_err
+from oracle import c_oracle
+from zignal_amd import _lib, multi
+from zignal_amd.device import DeviceBuffer, sync
+from zignal_amd.measure.mls import TAPS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def comm1():
+    c = multi.Comm(multi.make_unique_id(), 0, 1, device=0)
+    yield c
+    c.close()
+
+
+def _oracle_all(N, taps, x):
+    ref = c_oracle.sequence(N, taps)
+    return np.stack([oracle_ir(N, taps, np.ascontiguousarray(x[:, c:c + 1], dtype=np.float64), ref) for c in range(x.shape[1])], axis=1)
+
+
+@pytest.mark.parametrize("N,C,R,dtype", [(9, 8, 5, "f64"), (12, 32, 6, "f64"), (13, 64, 4, "f32"), (12, 6, 3, "f64")])
+def test_two_emulated_ranks_step_by_step(N, C, R, dtype):
+    """Rank r holds periods r, r+2, ...; each adds its periods up on the GPU into the send layout; the host
+    adds the two send buffers (what ncclReduceScatter(sum) does) and gives block q back to 'rank' q, which
+    transforms it on the GPU."""
+    taps = TAPS[N][0]
+    p = plan(N, taps, dtype)
+    L, P = p.L, 2
+    npdt = p.np_dtype
+    rng = np.random.default_rng(N * 100 + C)
+    x = rng.standard_normal((R * L, C)).astype(npdt)
+    share = C // P
+    sends = []
+    for r in range(P):
+        periods, skip, total = multi.period_shard(R, P, r)
+        local = np.ascontiguousarray(np.concatenate([x[q * L:(q + 1) * L] for q in periods], axis=0))
+        d_x = DeviceBuffer(local.nbytes).upload(local)
+        d_s = DeviceBuffer(P * L * share * local.itemsize)
+        d_s.fill(0xFF)
+        multi.period_sum_device(p, d_x.ptr, p.dtype_code, local.shape[0], skip, C, 1, P, share, 0, share, d_s.ptr)
+        got = d_s.download((P, L, share), npdt)
+        want = np.zeros((L, C), dtype=npdt)
+        for i in range(skip, len(periods)):
+            want += local[i * L:(i + 1) * L]
+        assert np.array_equal(got, multi.send_layout(want, P)), "partial period sums of rank %d differ" % r
+        sends.append(got)
+    summed = sends[0] + sends[1]
+    want_h = _oracle_all(N, taps, x)
+    tol = 1e-12 if dtype == "f64" else 1e-5
+    for q in range(P):
+        first, n = multi.exchange_block(C, P, q)
+        d_blk = DeviceBuffer(summed[q].nbytes).upload(summed[q])
+        d_h = DeviceBuffer(L * n * summed.itemsize)
+        p.reserve(n)
+        multi.impulse_sums_device(p, d_blk.ptr, R - 1, n, n, 1, d_h.ptr, n, 1)
+        h = d_h.download((L, n), npdt)
+        assert rel_err(h, want_h[:, first:first + n]) <= tol
+
+
+def test_rccl_collectives_on_a_one_rank_communicator(comm1):
+    a = np.arange(1000, dtype=np.float64)
+    d_a, d_b = DeviceBuffer(a.nbytes).upload(a), DeviceBuffer(a.nbytes)
+    d_b.fill(0)
+    comm1.reduce_scatter_device(d_a.ptr, d_b.ptr, a.size, _lib.ZMLS_F64)
+    sync(0)
+    assert np.array_equal(d_b.download(a.shape, np.float64), a)
+    d_b.fill(0)
+    comm1.all_gather_device(d_a.ptr, d_b.ptr, a.size, _lib.ZMLS_F64)
+    sync(0)
+    assert np.array_equal(d_b.download(a.shape, np.float64), a)
+    assert comm1.info()["world"] == 1
+
+
+@pytest.mark.parametrize("N,C,R,chunk,dtype", [(12, 48, 5, 16, "f64"), (14, 32, 3, 32, "f64"), (9, 12, 4, 5, "f64"),
+                                              (13, 64, 9, 16, "f32")])
+def test_fused_entry_point_one_rank_against_impulse_device_and_oracle(comm1, N, C, R, chunk, dtype):
+    taps = TAPS[N][0]
+    p = plan(N, taps, dtype)
+    L = p.L
+    npdt = p.np_dtype
+    rng = np.random.default_rng(N + C + R)
+    x = rng.standard_normal((R * L, C)).astype(npdt)
+    d_x = DeviceBuffer(x.nbytes).upload(x)
+    d_h1, d_h2 = DeviceBuffer(L * C * x.itemsize), DeviceBuffer(L * C * x.itemsize)
+    d_h1.fill(0xFF)
+    d_h2.fill(0xFF)
+    p.reserve(C)
+    p.impulse_device(d_x.ptr, p.dtype_code, R * L, C, C, 1, d_h1.ptr, C, 1)
+    ps = multi.PeriodSharded(p, comm1, chunk)
+    ps.impulse_device(d_x.ptr, p.dtype_code, R * L, 1, R - 1, C, C, 1, d_h2.ptr, C, 1)
+    sync(0)
+    h1, h2 = d_h1.download((L, C), npdt), d_h2.download((L, C), npdt)
+    tol = 1e-12 if dtype == "f64" else 1e-5
+    assert rel_err(h2, h1.astype(np.float64)) <= (4e-16 if dtype == "f64" else 4e-7)     # same sums, same transform
+    assert rel_err(h2, _oracle_all(N, taps, x)) <= tol
+    # twice in a row on the same staging buffers, second time with fewer channels
+    C2 = chunk
+    d_h2.fill(0xFF)
+    ps.impulse_device(d_x.ptr, p.dtype_code, R * L, 1, R - 1, C2, C, 1, d_h2.ptr, C2, 1)
+    sync(0)
+    assert rel_err(d_h2.download((L, C2), npdt), h1[:, :C2].astype(np.float64)) <= (4e-16 if dtype == "f64" else 4e-7)
+
+
+def test_fused_entry_point_integer_capture_major_input(comm1):
+    N, C, R = 12, 8, 4
+    taps = TAPS[N][0]
+    p = plan(N, taps)
+    L = p.L
+    rng = np.random.default_rng(5)
+    x = rng.integers(-2000, 2000, size=(C, R * L)).astype(np.int16)            # (C, R*L): a stack of single-channel captures
+    d_x = DeviceBuffer(x.nbytes).upload(x)
+    d_h = DeviceBuffer(L * C * 8)
+    ps = multi.PeriodSharded(p, comm1, 8)
+    ps.impulse_device(d_x.ptr, _lib.ZMLS_I16, R * L, 1, R - 1, C, 1, R * L, d_h.ptr, C, 1)
+    sync(0)
+    h = d_h.download((L, C), np.float64)
+    assert rel_err(h, _oracle_all(N, taps, x.T.astype(np.float64))) <= 1e-12
+
+
+def test_fused_entry_point_argument_errors(comm1):
+    N = 10
+    p = plan(N, TAPS[N][0])
+    L = p.L
+    d = DeviceBuffer(2 * L * 8 * 8)
+    ps = multi.PeriodSharded(p, comm1, 8)
+    with pytest.raises(_lib.ZmlsError):     # frames not a multiple of L
+        ps.impulse_device(d.ptr, _lib.ZMLS_F64, 2 * L - 1, 1, 1, 8, 8, 1, d.ptr, 8, 1)
+    with pytest.raises(_lib.ZmlsError):     # more local periods than the stated total
+        ps.impulse_device(d.ptr, _lib.ZMLS_F64, 2 * L, 0, 1, 8, 8, 1, d.ptr, 8, 1)
+    p2 = plan(11, TAPS[11][0])
+    with pytest.raises(_lib.ZmlsError):     # staging was reserved for another plan
+        multi.PeriodSharded.impulse_device(type("X", (), {"plan": p2, "comm": comm1})(), d.ptr, _lib.ZMLS_F64, 2 * p2.L, 1, 1, 8, 8, 1, d.ptr, 8, 1)

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libzmls.so")
 
 ZMLS_F64, ZMLS_F32, ZMLS_I16, ZMLS_I32 = 0, 1, 2, 3
-E_ARG, E_HIP, E_NODEVICE, E_WORKSPACE, E_UNSUPPORTED = -1, -2, -3, -4, -5
+E_ARG, E_HIP, E_NODEVICE, E_WORKSPACE, E_UNSUPPORTED, E_COMM = -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
 
 _DT = {np.dtype(np.float64): ZMLS_F64, np.dtype(np.float32): ZMLS_F32,
        np.dtype(np.int16): ZMLS_I16, np.dtype(np.int32): ZMLS_I32}
@@ -40,6 +41,17 @@ SIGNATURES = {
                                   ctypes.POINTER(ctypes.c_float)],
     "zmls_impulse_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64],
     "zmls_average_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp],
+    "zmls_comm_unique_id": [c_vp],
+    "zmls_comm_create": [_vpp, c_vp, c_int, c_int, c_int],
+    "zmls_comm_destroy": [c_vp],
+    "zmls_comm_info": [c_vp, ctypes.POINTER(c_i64)],
+    "zmls_comm_reserve": [c_vp, c_vp, c_i64],
+    "zmls_comm_reduce_scatter_device": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    "zmls_comm_all_gather_device": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    "zmls_period_sum_device": [c_vp, c_vp, c_int, c_i64, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp],
+    "zmls_impulse_sums_device": [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],
+    "zmls_impulse_period_sharded_device": [c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64,
+                                           c_i64, c_vp],
     "zmls_synth_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_u64, ctypes.c_double, c_vp],
     "zmls_synth_system": [c_vp, c_i64, c_u64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)],
     "zmls_dev_alloc": [c_int, _vpp, c_sz],

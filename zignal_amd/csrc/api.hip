@@ -6,7 +6,6 @@
 
 namespace zmls {
 int validate_taps(int N, const int32_t *taps, int ntaps, uint32_t *G, uint32_t *s0);
-namespace {
 
 size_t dtype_size(int dt)
 {
@@ -47,6 +46,8 @@ hipError_t settled_malloc(void **ptr, size_t bytes)
     }
     return hipMalloc(ptr, bytes);
 }
+
+namespace {
 
 __global__ void count_sentinels_kernel(const uint32_t *t, uint64_t n, unsigned long long *count)
 {
@@ -245,21 +246,21 @@ int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
     return ZMLS_OK;
 }
 
-static int impulse_device_impl(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
-                               int64_t ch_stride, void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *stream,
-                               hipEvent_t *ev /* 2 per pass, or null */, float *pass_ms /* accumulated, or null */)
+} // extern "C"
+
+namespace zmls {
+int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
+                        int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
+                        int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev /* 2 per pass, or null */,
+                        float *pass_ms /* accumulated, or null */)
 {
     if (!p || !d_x || !d_h) { set_error("null argument"); return ZMLS_E_ARG; }
     if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
     if (n_ch < 1) { set_error("need at least one channel"); return ZMLS_E_ARG; }
-    if (n_rows <= p->L) { set_error("The first sequence will be thrown away: need more than L=%lld frames", (long long)p->L); return ZMLS_E_ARG; }
-    if (n_rows % p->L) { set_error("frame count %lld is not a multiple of L=%lld", (long long)n_rows, (long long)p->L); return ZMLS_E_ARG; }
     if (row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("strides must be positive"); return ZMLS_E_ARG; }
-    const int64_t periods = n_rows / p->L - 1;
-    if (periods > 0x7FFFFFFF) { set_error("too many periods"); return ZMLS_E_ARG; }
+    if (periods < 1 || periods > 0x7FFFFFFF || divisor < 1 || divisor > 0x7FFFFFFF) { set_error("period count out of range"); return ZMLS_E_ARG; }
     int rc = use_device(p->device);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
 
     const size_t ts = dtype_size(p->dtype);
     const int E = (int)(kVecBytes / ts);
@@ -285,7 +286,7 @@ static int impulse_device_impl(zmls_plan *p, const void *d_x, int in_dtype, int6
     PassArgs a;
     memset(&a, 0, sizeof a);
     a.N = p->N;
-    a.x = d_x; a.in_dtype = in_dtype; a.periods = (int)periods; a.L = p->L;
+    a.x = d_x; a.in_dtype = in_dtype; a.periods = (int)periods; a.skip_periods = skip_periods; a.divisor = (int)divisor; a.L = p->L;
     a.row_stride = row_stride; a.ch_stride = ch_stride; a.n_ch = n_ch;
     a.gather = p->d_gather;
     a.nt_loads = p->nt_loads;
@@ -355,12 +356,31 @@ static int impulse_device_impl(zmls_plan *p, const void *d_x, int in_dtype, int6
     }
     return ZMLS_OK;
 }
+} // namespace zmls
+
+namespace {
+// a capture of R >= 2 periods: the first is thrown away, the rest are averaged (mls.py:284-306, 322-323)
+int capture_periods(const zmls_plan *p, int64_t n_rows, int64_t *periods)
+{
+    if (!p) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (n_rows <= p->L) { set_error("The first sequence will be thrown away: need more than L=%lld frames", (long long)p->L); return ZMLS_E_ARG; }
+    if (n_rows % p->L) { set_error("frame count %lld is not a multiple of L=%lld", (long long)n_rows, (long long)p->L); return ZMLS_E_ARG; }
+    *periods = n_rows / p->L - 1;
+    if (*periods > 0x7FFFFFFF) { set_error("too many periods"); return ZMLS_E_ARG; }
+    return ZMLS_OK;
+}
+} // namespace
+
+extern "C" {
 
 int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
                         int64_t ch_stride, void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *stream)
 {
-    return impulse_device_impl(p, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride,
-                               stream, nullptr, nullptr);
+    int64_t periods = 0;
+    int rc = capture_periods(p, n_rows, &periods);
+    if (rc) return rc;
+    return impulse_device_core(p, d_x, in_dtype, periods, 1, periods, n_ch, row_stride, ch_stride, d_h, out_row_stride,
+                               out_ch_stride, (hipStream_t)stream, nullptr, nullptr);
 }
 
 int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
@@ -368,7 +388,10 @@ int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64
                               float pass_ms[4])
 {
     if (!p || !pass_ms) { set_error("null argument"); return ZMLS_E_ARG; }
-    int rc = use_device(p->device);
+    int64_t periods = 0;
+    int rc = capture_periods(p, n_rows, &periods);
+    if (rc) return rc;
+    rc = use_device(p->device);
     if (rc) return rc;
     hipEvent_t ev[8];
     int made = 0;
@@ -376,8 +399,8 @@ int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64
         if (hipEventCreate(&ev[made]) != hipSuccess) break;
     for (int i = 0; i < 4; ++i) pass_ms[i] = 0.f;
     if (made == 8)
-        rc = impulse_device_impl(p, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride,
-                                 stream, ev, pass_ms);
+        rc = impulse_device_core(p, d_x, in_dtype, periods, 1, periods, n_ch, row_stride, ch_stride, d_h, out_row_stride,
+                                 out_ch_stride, (hipStream_t)stream, ev, pass_ms);
     else { set_error("could not create HIP events"); rc = ZMLS_E_HIP; }
     for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
     return rc;

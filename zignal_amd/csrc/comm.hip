@@ -1,0 +1,309 @@
+// Multi-GPU: one process per GPU, RCCL over xGMI for the one exchange the path has.
+//
+// Channels are independent, so the normal way to use several GPUs needs nothing from this file: every
+// rank runs zmls_impulse_device on its own channels. This file is for captures whose PERIODS are spread
+// over the GPUs (second mode): trim_and_avgerage (zignal/measure/mls.py:284-306) is a
+// sum over periods and xcorr_circular (mls.py:169-256) is linear, so every rank adds up the periods it
+// holds (period_sum.hip), the partial sums are reduce-scattered over the channel axis (rank q receives
+// the complete sums of channel block q), and rank q divides, transforms and scatters its block locally.
+// Reducing before the transform moves the same bytes as reducing after it and needs 1/P of the transforms.
+//
+// The exchange is chunked over channels and double-buffered: while RCCL moves chunk k on the communicator's
+// own stream, the caller's stream adds up chunk k+1 and transforms chunk k-1.
+//
+// librccl is loaded on first use (dlopen), so single-GPU users never pay for it.
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
+#include <rccl/rccl.h>
+#include "zmls_internal.h"
+
+namespace zmls {
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    char why[256] = "";
+    bool ok = false;
+    Rccl()
+    {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        if (!handle) { snprintf(why, sizeof why, "cannot load librccl: %s", dlerror()); return; }
+#define ZSYM(field, name)                                                                      \
+    field = (decltype(field))dlsym(handle, name);                                              \
+    if (!field) { snprintf(why, sizeof why, "librccl has no symbol %s", name); return; }
+        ZSYM(GetUniqueId, "ncclGetUniqueId")
+        ZSYM(CommInitRank, "ncclCommInitRank")
+        ZSYM(CommDestroy, "ncclCommDestroy")
+        ZSYM(ReduceScatter, "ncclReduceScatter")
+        ZSYM(AllGather, "ncclAllGather")
+        ZSYM(GetErrorString, "ncclGetErrorString")
+#undef ZSYM
+        ok = true;
+    }
+};
+
+Rccl *rccl()
+{
+    static Rccl r;      // loaded once, thread-safe
+    if (!r.ok) { set_error("%s", r.why); return nullptr; }
+    return &r;
+}
+
+#define ZNCCL(R, call)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r__ = (call);                                                              \
+        if (r__ != ncclSuccess) { set_error("RCCL error %d (%s) in %s", (int)r__, (R)->GetErrorString(r__), #call); return ZMLS_E_COMM; } \
+    } while (0)
+
+ncclDataType_t nccl_type(int dtype) { return dtype == ZMLS_F64 ? ncclFloat64 : ncclFloat32; }
+
+} // namespace
+} // namespace zmls
+
+struct zmls_comm {
+    int rank, n_ranks, device;
+    ncclComm_t nccl;
+    hipStream_t cs;             // the collectives run here, beside the caller's stream
+    hipEvent_t e_sum[2], e_rs[2];
+    void *d_send[2], *d_recv[2];
+    size_t send_bytes, recv_bytes;   // per buffer
+    int64_t chunk_ch;           // channels of one rank's share that go through the exchange at a time
+    int staging_dtype;
+    int64_t staging_L;
+};
+
+using namespace zmls;
+
+static void free_staging(zmls_comm *c)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (c->d_send[i]) (void)hipFree(c->d_send[i]);
+        if (c->d_recv[i]) (void)hipFree(c->d_recv[i]);
+        c->d_send[i] = c->d_recv[i] = nullptr;
+    }
+    c->send_bytes = c->recv_bytes = 0;
+    c->chunk_ch = 0;
+}
+
+extern "C" {
+
+int zmls_comm_unique_id(uint8_t *id)
+{
+    if (!id) { set_error("null id"); return ZMLS_E_ARG; }
+    Rccl *R = rccl();
+    if (!R) return ZMLS_E_COMM;
+    static_assert(sizeof(ncclUniqueId) == ZMLS_COMM_ID_BYTES, "id size");
+    ncclUniqueId u;
+    ZNCCL(R, R->GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return ZMLS_OK;
+}
+
+int zmls_comm_create(zmls_comm **out, const uint8_t *id, int rank, int n_ranks, int device)
+{
+    if (!out || !id) { set_error("null argument"); return ZMLS_E_ARG; }
+    *out = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) { set_error("rank %d outside 0..%d", rank, n_ranks - 1); return ZMLS_E_ARG; }
+    int rc = use_device(device);
+    if (rc) return rc;
+    Rccl *R = rccl();
+    if (!R) return ZMLS_E_COMM;
+    zmls_comm *c = (zmls_comm *)calloc(1, sizeof(zmls_comm));
+    if (!c) { set_error("out of host memory"); return ZMLS_E_ARG; }
+    c->rank = rank; c->n_ranks = n_ranks; c->device = device;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclResult_t r = R->CommInitRank(&c->nccl, n_ranks, u, rank);
+    if (r != ncclSuccess) {
+        set_error("RCCL error %d (%s) in ncclCommInitRank(rank %d of %d)", (int)r, R->GetErrorString(r), rank, n_ranks);
+        free(c);
+        return ZMLS_E_COMM;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&c->e_sum[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->e_rs[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        rc = hip_fail(e, "communicator stream/events");
+        (void)zmls_comm_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return ZMLS_OK;
+}
+
+int zmls_comm_destroy(zmls_comm *c)
+{
+    if (!c) return ZMLS_OK;
+    if (hipSetDevice(c->device) == hipSuccess) {
+        (void)hipDeviceSynchronize();
+        free_staging(c);
+        for (int i = 0; i < 2; ++i) {
+            if (c->e_sum[i]) (void)hipEventDestroy(c->e_sum[i]);
+            if (c->e_rs[i]) (void)hipEventDestroy(c->e_rs[i]);
+        }
+        if (c->cs) (void)hipStreamDestroy(c->cs);
+    }
+    Rccl *R = rccl();
+    if (R && c->nccl) (void)R->CommDestroy(c->nccl);
+    free(c);
+    return ZMLS_OK;
+}
+
+int zmls_comm_info(const zmls_comm *c, int64_t info[8])
+{
+    if (!c || !info) { set_error("null argument"); return ZMLS_E_ARG; }
+    memset(info, 0, sizeof(int64_t) * 8);
+    info[0] = c->rank; info[1] = c->n_ranks; info[2] = c->device; info[3] = c->chunk_ch;
+    info[4] = (int64_t)(2 * (c->send_bytes + c->recv_bytes));
+    return ZMLS_OK;
+}
+
+int zmls_comm_reserve(zmls_comm *c, zmls_plan *p, int64_t chunk_ch)
+{
+    if (!c || !p || chunk_ch < 1) { set_error("bad reserve arguments"); return ZMLS_E_ARG; }
+    if (p->device != c->device) { set_error("plan is on device %d, communicator on device %d", p->device, c->device); return ZMLS_E_ARG; }
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    rc = zmls_plan_reserve(p, chunk_ch);
+    if (rc) return rc;
+    const size_t recv = (size_t)p->L * (size_t)chunk_ch * dtype_size(p->dtype);
+    const size_t send = recv * (size_t)c->n_ranks;
+    if (send <= c->send_bytes && recv <= c->recv_bytes && c->staging_dtype == p->dtype && c->staging_L == p->L) {
+        c->chunk_ch = chunk_ch;
+        return ZMLS_OK;
+    }
+    ZHIP(hipDeviceSynchronize());
+    free_staging(c);
+    for (int i = 0; i < 2; ++i) {
+        ZHIP(settled_malloc(&c->d_send[i], send));
+        ZHIP(settled_malloc(&c->d_recv[i], recv));
+    }
+    c->send_bytes = send; c->recv_bytes = recv; c->chunk_ch = chunk_ch;
+    c->staging_dtype = p->dtype; c->staging_L = p->L;
+    return ZMLS_OK;
+}
+
+int zmls_comm_reduce_scatter_device(zmls_comm *c, const void *d_send, void *d_recv, int64_t recv_count, int dtype, void *stream)
+{
+    if (!c || !d_send || !d_recv || recv_count < 1) { set_error("bad reduce_scatter arguments"); return ZMLS_E_ARG; }
+    if (dtype != ZMLS_F64 && dtype != ZMLS_F32) { set_error("reduce_scatter moves f64 or f32"); return ZMLS_E_ARG; }
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    Rccl *R = rccl();
+    if (!R) return ZMLS_E_COMM;
+    ZNCCL(R, R->ReduceScatter(d_send, d_recv, (size_t)recv_count, nccl_type(dtype), ncclSum, c->nccl, (hipStream_t)stream));
+    return ZMLS_OK;
+}
+
+int zmls_comm_all_gather_device(zmls_comm *c, const void *d_send, void *d_recv, int64_t send_count, int dtype, void *stream)
+{
+    if (!c || !d_send || !d_recv || send_count < 1) { set_error("bad all_gather arguments"); return ZMLS_E_ARG; }
+    if (dtype != ZMLS_F64 && dtype != ZMLS_F32) { set_error("all_gather moves f64 or f32"); return ZMLS_E_ARG; }
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    Rccl *R = rccl();
+    if (!R) return ZMLS_E_COMM;
+    ZNCCL(R, R->AllGather(d_send, d_recv, (size_t)send_count, nccl_type(dtype), c->nccl, (hipStream_t)stream));
+    return ZMLS_OK;
+}
+
+int zmls_period_sum_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int skip_periods, int64_t row_stride,
+                           int64_t ch_stride, int64_t n_blocks, int64_t block_ch_stride, int64_t ch_first, int64_t block_ch,
+                           void *d_out, void *stream)
+{
+    if (!p || !d_x || !d_out) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
+    if (skip_periods < 0 || n_rows < 1 || n_rows % p->L || n_rows / p->L <= skip_periods) {
+        set_error("frame count %lld must be a multiple of L=%lld holding more than the %d skipped period(s)", (long long)n_rows, (long long)p->L, skip_periods);
+        return ZMLS_E_ARG;
+    }
+    if (row_stride < 1 || ch_stride < 1 || n_blocks < 1 || block_ch_stride < 0 || ch_first < 0 || block_ch < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    return launch_period_sum(d_x, in_dtype, p->dtype, p->L, n_rows / p->L - skip_periods, skip_periods, row_stride, ch_stride, n_blocks,
+                             block_ch_stride, ch_first, block_ch, d_out, (hipStream_t)stream);
+}
+
+int zmls_impulse_sums_device(zmls_plan *p, const void *d_s, int64_t total_periods, int64_t n_ch, int64_t row_stride, int64_t ch_stride,
+                             void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *stream)
+{
+    if (!p) { set_error("null argument"); return ZMLS_E_ARG; }
+    return impulse_device_core(p, d_s, p->dtype, 1, 0, total_periods, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride,
+                               (hipStream_t)stream, nullptr, nullptr);
+}
+
+int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d_x, int in_dtype, int64_t n_rows, int skip_periods,
+                                       int64_t total_periods, int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h,
+                                       int64_t out_row_stride, int64_t out_ch_stride, void *stream)
+{
+    if (!p || !c || !d_h) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (p->device != c->device) { set_error("plan is on device %d, communicator on device %d", p->device, c->device); return ZMLS_E_ARG; }
+    if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
+    if (n_rows < 0 || n_rows % p->L || skip_periods < 0 || n_rows / p->L < skip_periods) {
+        set_error("frame count %lld must be a multiple of L=%lld holding the %d skipped period(s)", (long long)n_rows, (long long)p->L, skip_periods);
+        return ZMLS_E_ARG;
+    }
+    const int64_t local_periods = n_rows / p->L - skip_periods;
+    if (local_periods > 0 && !d_x) { set_error("null capture"); return ZMLS_E_ARG; }
+    if (total_periods < 1 || total_periods > 0x7FFFFFFF || local_periods > total_periods) { set_error("total period count %lld out of range", (long long)total_periods); return ZMLS_E_ARG; }
+    if (n_ch < 1 || n_ch % c->n_ranks) { set_error("%lld channels do not split evenly over %d ranks", (long long)n_ch, c->n_ranks); return ZMLS_E_ARG; }
+    if (row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("strides must be positive"); return ZMLS_E_ARG; }
+    if (c->chunk_ch < 1 || c->staging_dtype != p->dtype || c->staging_L != p->L) { set_error("call zmls_comm_reserve(comm, plan, chunk_channels) first"); return ZMLS_E_WORKSPACE; }
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    Rccl *R = rccl();
+    if (!R) return ZMLS_E_COMM;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ts = dtype_size(p->dtype);
+    const int64_t share = n_ch / c->n_ranks;                 // channels this rank ends up with
+    const int64_t n_chunks = (share + c->chunk_ch - 1) / c->chunk_ch;
+
+    auto add_up = [&](int64_t k) -> int {
+        const int buf = (int)(k & 1);
+        const int64_t cc = (share - k * c->chunk_ch < c->chunk_ch) ? share - k * c->chunk_ch : c->chunk_ch;
+        if (local_periods == 0) ZHIP(hipMemsetAsync(c->d_send[buf], 0, (size_t)c->n_ranks * p->L * cc * ts, st));
+        else {
+            int r = launch_period_sum(d_x, in_dtype, p->dtype, p->L, local_periods, skip_periods, row_stride, ch_stride, c->n_ranks, share,
+                                      k * c->chunk_ch, cc, c->d_send[buf], st);
+            if (r) return r;
+        }
+        ZHIP(hipEventRecord(c->e_sum[buf], st));
+        ZHIP(hipStreamWaitEvent(c->cs, c->e_sum[buf], 0));
+        ZNCCL(R, R->ReduceScatter(c->d_send[buf], c->d_recv[buf], (size_t)(p->L * cc), nccl_type(p->dtype), ncclSum, c->nccl, c->cs));
+        ZHIP(hipEventRecord(c->e_rs[buf], c->cs));
+        return ZMLS_OK;
+    };
+
+    // chunk k+1 is added up and handed to RCCL before chunk k is transformed; send/recv buffer k&1 is
+    // free again by stream order (chunk k+2 is issued on `st` after the transform of chunk k)
+    rc = add_up(0);
+    if (rc) return rc;
+    for (int64_t k = 0; k < n_chunks; ++k) {
+        if (k + 1 < n_chunks) {
+            rc = add_up(k + 1);
+            if (rc) return rc;
+        }
+        const int buf = (int)(k & 1);
+        const int64_t cc = (share - k * c->chunk_ch < c->chunk_ch) ? share - k * c->chunk_ch : c->chunk_ch;
+        ZHIP(hipStreamWaitEvent(st, c->e_rs[buf], 0));
+        rc = impulse_device_core(p, c->d_recv[buf], p->dtype, 1, 0, total_periods, cc, cc, 1,
+                                 (char *)d_h + (size_t)(k * c->chunk_ch * out_ch_stride) * ts, out_row_stride, out_ch_stride, st, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return ZMLS_OK;
+}
+
+} // extern "C"

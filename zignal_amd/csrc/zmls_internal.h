@@ -71,7 +71,9 @@ struct PassArgs {
     // gather-in
     const void *x;
     int in_dtype;
-    int periods;              // R - 1 averaged periods
+    int periods;              // periods added up, starting at period skip_periods of the buffer
+    int skip_periods;         // 1: the buffer starts with the period the reference throws away (mls.py:284)
+    int divisor;              // the sum is divided by this (= periods, unless it is a partial sum)
     int64_t L;
     int64_t row_stride, ch_stride;   // elements
     int64_t n_ch;             // channels of the capture
@@ -82,6 +84,14 @@ struct PassArgs {
     int64_t out_row_stride, out_ch_stride;
     const uint32_t *scatter;  // last pass's thread order (single: natural order)
 };
+
+// the launch sequence of one impulse-response batch (api.hip); ev/pass_ms null unless timed
+int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
+                        int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
+                        int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms);
+size_t dtype_size(int dt);
+int use_device(int device);
+hipError_t settled_malloc(void **ptr, size_t bytes);
 
 int launch_pass_f64(int cfg, int K, int inm, int outm, const PassArgs &a, hipStream_t st);
 int launch_pass_f32(int cfg, int K, int inm, int outm, const PassArgs &a, hipStream_t st);
@@ -99,6 +109,9 @@ int launch_synth(const uint32_t *d_bits, int64_t L, void *d_x, int dtype, int64_
 int launch_average(const void *d_x, int in_dtype, int64_t L, int64_t periods, int64_t n_ch, int64_t row_stride,
                    int64_t ch_stride, void *d_out, hipStream_t st);
 void synth_system(int64_t L, int64_t channel, uint64_t seed, double *taps, int64_t *delay);
+int launch_period_sum(const void *d_x, int in_dtype, int out_dtype, int64_t L, int64_t periods, int skip_periods,
+                      int64_t row_stride, int64_t ch_stride, int64_t n_blocks, int64_t block_ch_stride, int64_t ch_first,
+                      int64_t block_ch, void *d_out, hipStream_t st);
 int launch_extract_channel(void *d_dst, const void *d_src, int dtype, int64_t n_rows, int64_t row_stride,
                            int64_t ch_stride, int64_t channel, hipStream_t st);
 
