@@ -99,6 +99,13 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
                       int64_t row_stride, int64_t ch_stride,
                       void *h, int64_t out_row_stride, int64_t out_ch_stride);
 
+/* Device buffer for an (n_rows, n_ch) C-contiguous capture of `in_dtype`, placed for this plan: where a large
+ * buffer lies in physical memory changes the speed of the gather pass by 5-25 % (measured; api.hip), so up to
+ * `tries` candidate allocations (0 = default 4) are rated with the plan's own gather pass and the fastest is kept;
+ * *probe_ms (may be null) receives its gather-pass time. Captures under 1 GiB are simply allocated. Free with
+ * zmls_dev_free. Allocates, launches and synchronises: plan-time only. No counterpart in the reference. */
+int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch, int tries, void **d_x, float *probe_ms);
+
 /* ---- the averaging step alone: replaces trim_and_avgerage (mls.py:258-313) when it is called
  * on its own. out: (L, n_ch) C-contiguous HOST buffer, float32 when in_dtype is ZMLS_F32 (numpy
  * averages float32 in float32), float64 otherwise. */

@@ -255,3 +255,31 @@ def test_big_tile_against_small_tile_and_oracle(N, C, dtype):
     for c in (0, C // 2 + 1, C - 1):
         want = oracle_ir(N, taps, np.ascontiguousarray(x[:, c:c + 1]).astype(np.float64), ref)
         assert rel_err(h_big[:, c], want) <= tol, (N, c)
+
+
+def test_capture_alloc_chooses_a_placement_and_the_buffer_works():
+    """zmls_capture_alloc: under 1 GiB a plain allocation (probe time 0); above, candidates are rated with the
+    plan's gather pass. Either way the buffer is an ordinary capture buffer."""
+    N = 18
+    taps = TAPS[N][0]
+    p = plan(N, taps)
+    L = p.L
+    for C, R, probed in ((16, 2, False), (256, 3, True)):
+        d_x, ms = p.alloc_capture(R * L, C, tries=2)
+        assert (ms > 0.0) == probed
+        assert d_x.nbytes == R * L * C * 8
+        p.reserve(C)
+        p.synth_device(d_x.ptr, _lib.ZMLS_F64, R, C, C, 1, seed=11, sigma=0.0)
+        d_h = DeviceBuffer(L * C * 8)
+        p.impulse_device(d_x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, d_h.ptr, C, 1)
+        h = d_h.download((L, C), np.float64)
+        for c in (0, C - 1):
+            g, d = p.synth_system(c, seed=11)
+            want = np.zeros(L)
+            want[(d + np.arange(16)) % L] = g
+            # two-valued autocorrelation (L at lag 0, -1 elsewhere): h = g (1 + 1/L) - sum(g)/L
+            want = want * (1.0 + 1.0 / L) - g.sum() / L
+            assert np.max(np.abs(h[:, c] - want)) <= 1e-12
+        d_x.free()
+    with pytest.raises(_lib.ZmlsError):
+        p.alloc_capture(L, 4)            # one period only: "The first sequence will be thrown away"

@@ -40,6 +40,7 @@ SIGNATURES = {
     "zmls_impulse_device_timed": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp,
                                   ctypes.POINTER(ctypes.c_float)],
     "zmls_impulse_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64],
+    "zmls_capture_alloc": [c_vp, c_int, c_i64, c_i64, c_int, _vpp, ctypes.POINTER(ctypes.c_float)],
     "zmls_average_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp],
     "zmls_comm_unique_id": [c_vp],
     "zmls_comm_create": [_vpp, c_vp, c_int, c_int, c_int],

@@ -252,9 +252,9 @@ namespace zmls {
 int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
                         int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
                         int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev /* 2 per pass, or null */,
-                        float *pass_ms /* accumulated, or null */)
+                        float *pass_ms /* accumulated, or null */, int gather_pass_only /* placement probe: stop after pass 1 */)
 {
-    if (!p || !d_x || !d_h) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (!p || !d_x || (!d_h && !gather_pass_only)) { set_error("null argument"); return ZMLS_E_ARG; }
     if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
     if (n_ch < 1) { set_error("need at least one channel"); return ZMLS_E_ARG; }
     if (row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("strides must be positive"); return ZMLS_E_ARG; }
@@ -328,7 +328,7 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
         a.work_slab_stride = p->work_layout ? U : work_rows_total(p->N) * U;
         a.work_row_stride = p->work_layout ? (uint64_t)ns * U : U;
         int b = 0;
-        for (int i = 0; i < p->npass; ++i) {
+        for (int i = 0; i < (gather_pass_only ? 1 : p->npass); ++i) {
             const int K = p->bits[i];
             const int LT = log2_tiles(K, tc);
             a.b = b;
@@ -347,7 +347,7 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
             b += K;
         }
         if (ev)
-            for (int i = 0; i < p->npass; ++i) {
+            for (int i = 0; i < (gather_pass_only ? 1 : p->npass); ++i) {
                 float ms = 0.f;
                 ZHIP(hipEventSynchronize(ev[2 * i + 1]));
                 ZHIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
@@ -380,7 +380,7 @@ int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_r
     int rc = capture_periods(p, n_rows, &periods);
     if (rc) return rc;
     return impulse_device_core(p, d_x, in_dtype, periods, 1, periods, n_ch, row_stride, ch_stride, d_h, out_row_stride,
-                               out_ch_stride, (hipStream_t)stream, nullptr, nullptr);
+                               out_ch_stride, (hipStream_t)stream, nullptr, nullptr, 0);
 }
 
 int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
@@ -400,7 +400,7 @@ int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64
     for (int i = 0; i < 4; ++i) pass_ms[i] = 0.f;
     if (made == 8)
         rc = impulse_device_core(p, d_x, in_dtype, periods, 1, periods, n_ch, row_stride, ch_stride, d_h, out_row_stride,
-                                 out_ch_stride, (hipStream_t)stream, ev, pass_ms);
+                                 out_ch_stride, (hipStream_t)stream, ev, pass_ms, 0);
     else { set_error("could not create HIP events"); rc = ZMLS_E_HIP; }
     for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
     return rc;
@@ -437,6 +437,83 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
     if (d_x) (void)hipFree(d_x);
     if (d_h) (void)hipFree(d_h);
     return rc;
+}
+
+// Where a capture lies in physical memory decides how fast the gather pass reads it: on MI355X / ROCm 7.2 the same
+// 73 GB capture (N=20, 512 channels, 17 periods) at the same virtual address is gathered in 12.6-12.8 ms on some
+// allocations and 13.3-15.6 ms on others, stable for the lifetime of the allocation (tools/alloc_probe.py; neither
+// hipDeviceMallocContiguous nor hipMemCreate/hipMemMap placement changed that). So a capture buffer is chosen:
+// candidates are allocated one after the other, each is rated with this plan's own gather pass, the fastest is
+// kept. Rejected candidates stay allocated while the search runs, so the driver cannot hand the same memory back.
+int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch, int tries, void **d_x, float *probe_ms)
+{
+    if (!p || !d_x) { set_error("null argument"); return ZMLS_E_ARG; }
+    *d_x = nullptr;
+    const size_t is = dtype_size(in_dtype);
+    if (!is) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
+    int64_t periods = 0;
+    int rc = capture_periods(p, n_rows, &periods);
+    if (rc) return rc;
+    if (n_ch < 1) { set_error("need at least one channel"); return ZMLS_E_ARG; }
+    if (tries < 1) tries = 4;
+    rc = use_device(p->device);
+    if (rc) return rc;
+    const size_t bytes = (size_t)n_rows * (size_t)n_ch * is;
+    // small captures, and plans that do everything in one LDS-resident pass, have nothing to choose
+    const bool probe = tries > 1 && p->npass > 1 && bytes >= ((size_t)1 << 30);
+    if (!probe) {
+        ZHIP(hipMalloc(d_x, bytes));
+        if (probe_ms) *probe_ms = 0.f;
+        return ZMLS_OK;
+    }
+    rc = zmls_plan_reserve(p, n_ch);
+    if (rc) return rc;
+    hipEvent_t ev[2];
+    ZHIP(hipEventCreate(&ev[0]));
+    ZHIP(hipEventCreate(&ev[1]));
+    void *best = nullptr, *rejected[2] = {nullptr, nullptr};
+    float best_ms = 0.f, second_ms = 0.f;
+    auto reject = [&](void *q) {
+        if (rejected[0]) (void)hipFree(rejected[0]);      // at most two rejected candidates are held at a time
+        rejected[0] = rejected[1];
+        rejected[1] = q;
+    };
+    for (int t = 0; t < tries; ++t) {
+        void *cand = nullptr;
+        hipError_t e = hipMalloc(&cand, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (!best) { rc = hip_fail(e, "hipMalloc(capture)"); }
+            break;                                        // memory is full of candidates: settle for the best so far
+        }
+        float ms = 0.f, pass_ms[4];
+        e = hipMemsetAsync(cand, 0, bytes, 0);
+        for (int rep = 0; rep < 3 && e == hipSuccess && !rc; ++rep) {     // first run warms up, the faster of the next two counts
+            pass_ms[0] = 0.f;
+            rc = impulse_device_core(p, cand, in_dtype, periods, 1, periods, n_ch, n_ch, 1, nullptr, n_ch, 1, 0, ev, pass_ms, 1);
+            if (rep == 1 || (rep == 2 && pass_ms[0] < ms)) ms = pass_ms[0];
+        }
+        if (e != hipSuccess && !rc) rc = hip_fail(e, "capture placement probe");
+        if (rc) { (void)hipFree(cand); break; }
+        if (!best || ms < best_ms) {
+            if (best) reject(best);
+            second_ms = best ? best_ms : 0.f;
+            best = cand; best_ms = ms;
+        } else {
+            if (second_ms == 0.f || ms < second_ms) second_ms = ms;
+            reject(cand);
+        }
+        // two candidates within 2 % of each other at the top: that is the floor, stop looking
+        if (second_ms > 0.f && second_ms <= best_ms * 1.02f) break;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (rejected[i]) (void)hipFree(rejected[i]);
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (rc) { if (best) (void)hipFree(best); return rc; }
+    *d_x = best;
+    if (probe_ms) *probe_ms = best_ms;
+    return ZMLS_OK;
 }
 
 int zmls_average_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,

@@ -242,7 +242,7 @@ int zmls_impulse_sums_device(zmls_plan *p, const void *d_s, int64_t total_period
 {
     if (!p) { set_error("null argument"); return ZMLS_E_ARG; }
     return impulse_device_core(p, d_s, p->dtype, 1, 0, total_periods, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride,
-                               (hipStream_t)stream, nullptr, nullptr);
+                               (hipStream_t)stream, nullptr, nullptr, 0);
 }
 
 int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d_x, int in_dtype, int64_t n_rows, int skip_periods,
@@ -300,7 +300,7 @@ int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d
         const int64_t cc = (share - k * c->chunk_ch < c->chunk_ch) ? share - k * c->chunk_ch : c->chunk_ch;
         ZHIP(hipStreamWaitEvent(st, c->e_rs[buf], 0));
         rc = impulse_device_core(p, c->d_recv[buf], p->dtype, 1, 0, total_periods, cc, cc, 1,
-                                 (char *)d_h + (size_t)(k * c->chunk_ch * out_ch_stride) * ts, out_row_stride, out_ch_stride, st, nullptr, nullptr);
+                                 (char *)d_h + (size_t)(k * c->chunk_ch * out_ch_stride) * ts, out_row_stride, out_ch_stride, st, nullptr, nullptr, 0);
         if (rc) return rc;
     }
     return ZMLS_OK;

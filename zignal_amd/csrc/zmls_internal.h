@@ -88,7 +88,7 @@ struct PassArgs {
 // the launch sequence of one impulse-response batch (api.hip); ev/pass_ms null unless timed
 int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
                         int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
-                        int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms);
+                        int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms, int gather_pass_only);
 size_t dtype_size(int dt);
 int use_device(int device);
 hipError_t settled_malloc(void **ptr, size_t bytes);

@@ -12,12 +12,14 @@ from . import _lib as L
 class DeviceBuffer:
     """hipMalloc'ed bytes owned by Python."""
 
-    def __init__(self, nbytes, device=0):
+    def __init__(self, nbytes, device=0, _ptr=None):
         self.device = device
         self.nbytes = int(nbytes)
-        p = ctypes.c_void_p()
-        L.check(L.lib().zmls_dev_alloc(device, ctypes.byref(p), self.nbytes))
-        self.ptr = p.value
+        if _ptr is None:
+            p = ctypes.c_void_p()
+            L.check(L.lib().zmls_dev_alloc(device, ctypes.byref(p), self.nbytes))
+            _ptr = p.value
+        self.ptr = _ptr
 
     def upload(self, arr):
         a = np.ascontiguousarray(arr)
@@ -88,6 +90,15 @@ class Plan:
 
     def reserve(self, n_ch):
         L.check(L.lib().zmls_plan_reserve(self._h, int(n_ch)))
+
+    def alloc_capture(self, n_rows, n_ch, dtype_code=None, tries=0):
+        """DeviceBuffer for an (n_rows, n_ch) C-contiguous capture, placed where this plan's gather pass reads it
+        fastest (zmls_capture_alloc). Returns (buffer, gather-pass milliseconds of the chosen placement or 0)."""
+        code = self.dtype_code if dtype_code is None else dtype_code
+        p, ms = ctypes.c_void_p(), ctypes.c_float()
+        L.check(L.lib().zmls_capture_alloc(self._h, code, int(n_rows), int(n_ch), int(tries), ctypes.byref(p), ctypes.byref(ms)))
+        nbytes = int(n_rows) * int(n_ch) * np.dtype(L.NP_OF[code]).itemsize
+        return DeviceBuffer(nbytes, self.device, _ptr=p.value), ms.value
 
     # -- sequence
     def bits_packed(self, nbits=None):
