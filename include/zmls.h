@@ -63,7 +63,7 @@ int zmls_plan_info(const zmls_plan *p, int64_t info[16]);
 /* Tile configuration used by the impulse entry points: -1 = chosen per call (default), 0 = small tile
  * (64 KiB, 64-byte row segments, any layout), 1 = big tile (256 KiB, 256-byte row segments), 2 = mid tile
  * (128 KiB, 128-byte row segments); 1 and 2 need contiguous, 16-byte aligned channels. Tuning bits: +256
- * switches the XCD-aware block mapping off, +512 gathers the capture with non-temporal loads. */
+ * switches the XCD-aware block mapping off, +1024 lays the workspace out row-major. */
 int zmls_plan_force_tile(zmls_plan *p, int cfg);
 
 /* ---- sequence: replaces generator_bit / generator_chunk / generator_samples /

@@ -192,8 +192,7 @@ int zmls_plan_force_tile(zmls_plan *p, int cfg)
 {
     if (!p || cfg < -1 || (cfg >= 0 && (cfg & 0xFF) >= CFG_COUNT)) { set_error("tile configuration must be -1 (auto), 0 (small), 1 (big) or 2 (mid)"); return ZMLS_E_ARG; }
     p->swizzle = (cfg >= 0 && (cfg & 0x100)) ? 0 : 1;     // +256: switch the XCD-aware block mapping off (tuning)
-    p->nt_loads = (cfg >= 0 && (cfg & 0x200)) ? 1 : 0;    // +512: non-temporal capture loads (tuning)
-    p->work_layout = (cfg >= 0 && (cfg & 0x400)) ? 1 : 0; // +1024: row-major workspace (tuning)
+        p->work_layout = (cfg >= 0 && (cfg & 0x400)) ? 1 : 0; // +1024: row-major workspace (tuning)
     p->force_cfg = cfg < 0 ? -1 : (cfg & 0xFF);
     return ZMLS_OK;
 }
@@ -289,7 +288,6 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
     a.x = d_x; a.in_dtype = in_dtype; a.periods = (int)periods; a.skip_periods = skip_periods; a.divisor = (int)divisor; a.L = p->L;
     a.row_stride = row_stride; a.ch_stride = ch_stride; a.n_ch = n_ch;
     a.gather = p->d_gather;
-    a.nt_loads = p->nt_loads;
     a.h = d_h; a.out_row_stride = out_row_stride; a.out_ch_stride = out_ch_stride;
 
     if (single) {

@@ -64,7 +64,6 @@ struct PassArgs {
     uint32_t n_macro;         // macro tiles per slab (single: 1)
     uint32_t n_slab_groups;   // slabs (single: groups of 2^LT slabs) in this launch
     uint32_t swz_group;       // XCD swizzle group size (0 = identity)
-    int nt_loads;             // gather the capture with non-temporal loads
     int slab_fastest;         // later passes: consecutive blocks are the slabs of one tile (else the tiles of one slab)
     void *work;               // row d of the transform of slab s at vector  s*work_slab_stride + work_row(d)*work_row_stride
     uint64_t work_slab_stride, work_row_stride;   // in 16-byte vectors: slab-major [slab][row][2^LU] or row-major [row][slab][2^LU]
@@ -138,6 +137,5 @@ struct zmls_plan {
     size_t work_bytes;
     int force_cfg;                // -1: choose per call; else a tile configuration (tests, tuning)
     int swizzle;                  // XCD-aware block mapping on/off (tuning)
-    int nt_loads;                 // non-temporal capture loads on/off (tuning)
     int work_layout;              // 0: workspace slab-major, 1: row-major with slab-fastest block order in every pass
 };
