@@ -1,0 +1,110 @@
+"""GPU parity at BASELINE.json's full single-GPU sizes (configs 2-5 and one GPU's share of config 3).
+
+The batches are far too large to push through the oracle, so every case is held to
+  * the oracle on a few channels pulled back from the device (bit-for-bit the same capture), and
+  * a size-independent property of every sampled channel: the synthetic channel c is the stimulus through a
+    known 16-tap FIR g_c delayed by d_c, and an MLS has a two-valued circular autocorrelation (L at lag 0, -1
+    elsewhere), so without noise the response must be  h = g_c(1 + 1/L) - sum(g_c)/L  at lag d_c, and
+    sum_m h[m] = -(1/L) sum_j avg[j]  for any capture.
+Captures are generated on the device (zmls_synth_device), in zignal's (frames, channels) layout.
+Tolerances: 1e-12 x peak for f64, 1e-5 x peak for the f32 mode (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from gpu_common import oracle_ir, rel_err
+from oracle import c_oracle
+from zignal_amd import _lib
+from zignal_amd.device import DeviceBuffer, Plan, download_channel, sync
+from zignal_amd.measure.mls import TAPS
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5A17
+
+
+def expected_noise_free(p, c, seed=SEED):
+    g, d = p.synth_system(c, seed)
+    want = np.zeros(p.L)
+    want[(d + np.arange(16)) % p.L] = g
+    return want * (1.0 + 1.0 / p.L) - g.sum() / p.L
+
+
+def run_batch(N, C, R, dtype, sigma):
+    p = Plan(N, TAPS[N][0], dtype=dtype, device=0)
+    es = 8 if dtype == "f64" else 4
+    d_x, _ = p.alloc_capture(R * p.L, C, tries=2)
+    d_h = DeviceBuffer(p.L * C * es)
+    d_h.fill(0xFF)
+    p.reserve(C)
+    p.synth_device(d_x.ptr, p.dtype_code, R, C, C, 1, seed=SEED, sigma=sigma)
+    p.impulse_device(d_x.ptr, p.dtype_code, R * p.L, C, C, 1, d_h.ptr, C, 1)
+    sync(0)
+    return p, d_x, d_h
+
+
+def channel(p, d_buf, n_rows, C, c):
+    return download_channel(0, d_buf.ptr, p.dtype_code, n_rows, C, 1, c).astype(np.float64)
+
+
+def check_channels(p, d_x, d_h, C, R, chans, tol, oracle_chans, sigma):
+    ref = c_oracle.sequence(p.N, p.taps)
+    for c in chans:
+        h = channel(p, d_h, p.L, C, c)
+        assert np.all(np.isfinite(h))
+        x = channel(p, d_x, R * p.L, C, c)
+        avg = x[p.L:].reshape(R - 1, p.L).mean(axis=0)
+        # sum of the response = -(1/L) sum of the averaged capture (autocorrelation sums to 1 per lag: L - (L-1))
+        assert abs(h.sum() + avg.sum() / p.L) <= tol * max(1.0, np.abs(avg).sum() / p.L) * (10 if tol < 1e-9 else 1000)
+        if sigma == 0.0:
+            assert np.max(np.abs(h - expected_noise_free(p, c))) <= tol
+        else:
+            # noise averages down by sqrt(periods * L): far below 1e-4 of the unit peak at these sizes
+            assert np.max(np.abs(h - expected_noise_free(p, c))) <= 1e-4
+        if c in oracle_chans:
+            assert rel_err(h, oracle_ir(p.N, p.taps, x.reshape(-1, 1), ref)) <= tol
+
+
+def test_config2_n18_64_channels_f64():
+    N, C, R = 18, 64, 2
+    p, d_x, d_h = run_batch(N, C, R, "f64", 1e-3)
+    assert p.info()["passes"] == 2
+    check_channels(p, d_x, d_h, C, R, range(0, C, 7), 1e-12, {0, 21, 63}, 1e-3)
+    p.close()
+
+
+def test_config3_share_n20_512_channels_16_periods_f64():
+    N, C, R = 20, 512, 17
+    p, d_x, d_h = run_batch(N, C, R, "f64", 1e-3)
+    check_channels(p, d_x, d_h, C, R, (0, 15, 16, 255, 511), 1e-12, {0, 511}, 1e-3)
+    d_x.free()
+    d_h.free()
+    p.close()
+
+
+def test_config4_n24_256_channels_three_passes_f64():
+    N, C, R = 24, 256, 2
+    p, d_x, d_h = run_batch(N, C, R, "f64", 0.0)
+    assert p.info()["passes"] == 3
+    check_channels(p, d_x, d_h, C, R, (0, 100, 255), 1e-12, {100}, 0.0)
+    d_x.free()
+    d_h.free()
+    p.close()
+
+
+def test_config5_n20_1024_channels_f32_against_f64():
+    N, C, R = 20, 1024, 2
+    p64, d_x64, d_h64 = run_batch(N, C, R, "f64", 1e-3)
+    chans = (0, 333, 1023)
+    h64 = {c: channel(p64, d_h64, p64.L, C, c) for c in chans}
+    check_channels(p64, d_x64, d_h64, C, R, chans, 1e-12, {333}, 1e-3)
+    d_x64.free()
+    d_h64.free()
+    p64.close()
+    p32, d_x32, d_h32 = run_batch(N, C, R, "f32", 1e-3)
+    for c in chans:
+        # same synthetic capture rounded to float32, float32 arithmetic: the accuracy side of the trade-off
+        assert rel_err(channel(p32, d_h32, p32.L, C, c), h64[c]) <= 1e-5
+    check_channels(p32, d_x32, d_h32, C, R, chans, 1e-5, {1023}, 1e-3)
+    d_x32.free()
+    d_h32.free()
+    p32.close()
