@@ -57,6 +57,14 @@ int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int
 int zmls_plan_destroy(zmls_plan *p);
 /* Make sure the workspace can hold `n_ch` channels in one go (allocates; call outside timed/captured regions). */
 int zmls_plan_reserve(zmls_plan *p, int64_t n_ch);
+/* Staging for captures / responses that are not 16-byte-aligned (frames, channels) arrays of the plan's dtype: a
+ * stack of single-channel captures (channels, frames) - what a batch of the reference's own inputs looks like -,
+ * int16/int32/float32 frames, odd channel counts. With staging for `n_ch` channels (2 arrays of L x n_ch elements;
+ * fewer: the batch runs in channel chunks) the device entry points first add the periods up into a frame-major
+ * array with coalesced reads and transpose the responses back at the end; without it they fall back to one
+ * element per lane, an order of magnitude slower on large batches. zmls_impulse_host reserves it itself.
+ * Allocates; call outside timed/captured regions. */
+int zmls_plan_reserve_staging(zmls_plan *p, int64_t n_ch);
 /* info[0]=N info[1]=L info[2]=dtype info[3]=device info[4]=number of FWHT passes
  * info[5..7]=bits per pass info[8]=workspace bytes info[9]/info[10]=channels per slab of the small/big tile */
 int zmls_plan_info(const zmls_plan *p, int64_t info[16]);

@@ -14,6 +14,7 @@ import inputs
 from gpu_common import G, case_input, load_json, oracle_ir, plan, rel_err
 from oracle import c_oracle, mls_oracle
 from zignal_amd import _lib
+from zignal_amd import _lib as L_
 from zignal_amd.device import DeviceBuffer
 from zignal_amd.measure.mls import MLS, TAPS, MLS_simple, _MLS_base
 
@@ -283,3 +284,47 @@ def test_capture_alloc_chooses_a_placement_and_the_buffer_works():
         d_x.free()
     with pytest.raises(_lib.ZmlsError):
         p.alloc_capture(L, 4)            # one period only: "The first sequence will be thrown away"
+
+
+@pytest.mark.parametrize("N,C,R,dtype,stage", [(12, 40, 4, "f64", 40), (13, 33, 3, "f64", 33), (14, 70, 5, "f64", 16), (13, 48, 3, "f32", 48),
+                                               (12, 1, 3, "f64", 1)])
+def test_layout_adapters_on_the_device_entry_point(N, C, R, dtype, stage):
+    """Captures stacked as (C, R*L) single-channel arrays in, responses (C, L) out, through the staged adapters
+    (periods summed + transposed in, transposed out), also in channel chunks when the staging arrays are smaller
+    than the batch, mixed with frame-major on one side, and int16 (frames, channels) input through the staged sum."""
+    from zignal_amd.device import Plan
+    taps = TAPS[N][0]
+    L = (1 << N) - 1
+    npdt = np.float64 if dtype == "f64" else np.float32
+    tol = TOL64 if dtype == "f64" else TOL32
+    rng = np.random.default_rng(N * 7 + C)
+    x = rng.standard_normal((R * L, C)).astype(npdt)
+    ref = c_oracle.sequence(N, taps)
+    want = np.stack([oracle_ir(N, taps, np.ascontiguousarray(x[:, c:c + 1]).astype(np.float64), ref) for c in range(C)], axis=1)
+    p = Plan(N, taps, dtype=dtype, device=0)
+    p.reserve(C)
+    L_.check(L_.lib().zmls_plan_reserve_staging(p._h, stage))
+    xt = np.ascontiguousarray(x.T)                         # (C, R*L)
+    d_x = DeviceBuffer(xt.nbytes).upload(xt)
+    d_h = DeviceBuffer(L * C * x.itemsize)
+    # capture-major in, capture-major out
+    d_h.fill(0xFF)
+    p.impulse_device(d_x.ptr, p.dtype_code, R * L, C, 1, R * L, d_h.ptr, 1, L)
+    assert rel_err(d_h.download((C, L), npdt).T, want) <= tol
+    # capture-major in, frame-major out
+    d_h.fill(0xFF)
+    p.impulse_device(d_x.ptr, p.dtype_code, R * L, C, 1, R * L, d_h.ptr, C, 1)
+    assert rel_err(d_h.download((L, C), npdt), want) <= tol
+    # frame-major in, capture-major out
+    d_f = DeviceBuffer(x.nbytes).upload(x)
+    d_h.fill(0xFF)
+    p.impulse_device(d_f.ptr, p.dtype_code, R * L, C, C, 1, d_h.ptr, 1, L)
+    assert rel_err(d_h.download((C, L), npdt).T, want) <= tol
+    # int16 frames (what a sound card hands over), frame-major both sides
+    xi = rng.integers(-30000, 30000, size=(R * L, C)).astype(np.int16)
+    want_i = np.stack([oracle_ir(N, taps, xi[:, c:c + 1].astype(np.float64), ref) for c in range(C)], axis=1)
+    d_i = DeviceBuffer(xi.nbytes).upload(xi)
+    d_h.fill(0xFF)
+    p.impulse_device(d_i.ptr, _lib.ZMLS_I16, R * L, C, C, 1, d_h.ptr, C, 1)
+    assert rel_err(d_h.download((L, C), npdt), want_i) <= tol
+    p.close()

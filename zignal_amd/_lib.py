@@ -31,6 +31,7 @@ SIGNATURES = {
     "zmls_plan_create": [_vpp, c_int, _i32p, c_int, c_int, c_int],
     "zmls_plan_destroy": [c_vp],
     "zmls_plan_reserve": [c_vp, c_i64],
+    "zmls_plan_reserve_staging": [c_vp, c_i64],
     "zmls_plan_force_tile": [c_vp, c_int],
     "zmls_plan_info": [c_vp, ctypes.POINTER(c_i64)],
     "zmls_sequence_bits": [c_vp, c_vp, c_i64],

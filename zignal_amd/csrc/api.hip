@@ -69,6 +69,8 @@ void free_plan_buffers(zmls_plan *p)
         if (p->d_scatter_perm[c]) (void)hipFree(p->d_scatter_perm[c]);
     if (p->d_jt) (void)hipFree(p->d_jt);
     if (p->d_work) (void)hipFree(p->d_work);
+    for (int i = 0; i < 2; ++i)
+        if (p->d_stage[i]) (void)hipFree(p->d_stage[i]);
 }
 
 int build_plan(zmls_plan *p)
@@ -188,6 +190,27 @@ int zmls_plan_reserve(zmls_plan *p, int64_t n_ch)
     return ZMLS_OK;
 }
 
+int zmls_plan_reserve_staging(zmls_plan *p, int64_t n_ch)
+{
+    if (!p || n_ch < 1) { set_error("bad reserve arguments"); return ZMLS_E_ARG; }
+    if (p->npass == 1) return ZMLS_OK;   // single-pass plans read and write any layout directly
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    const size_t ts = dtype_size(p->dtype);
+    const int64_t E = (int64_t)(kVecBytes / ts);
+    const size_t need = (size_t)p->L * (size_t)((n_ch + E - 1) / E * E) * ts;
+    rc = zmls_plan_reserve(p, (n_ch + E - 1) / E * E);
+    if (rc) return rc;
+    if (need <= p->stage_bytes) return ZMLS_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (p->d_stage[i]) { ZHIP(hipFree(p->d_stage[i])); p->d_stage[i] = nullptr; }
+    }
+    p->stage_bytes = 0;
+    for (int i = 0; i < 2; ++i) ZHIP(settled_malloc(&p->d_stage[i], need));
+    p->stage_bytes = need;
+    return ZMLS_OK;
+}
+
 int zmls_plan_force_tile(zmls_plan *p, int cfg)
 {
     if (!p || cfg < -1 || (cfg >= 0 && (cfg & 0xFF) >= CFG_COUNT)) { set_error("tile configuration must be -1 (auto), 0 (small), 1 (big) or 2 (mid)"); return ZMLS_E_ARG; }
@@ -248,7 +271,8 @@ int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
 } // extern "C"
 
 namespace zmls {
-int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
+// the launch sequence of the passes on buffers as they are (no layout adapters)
+static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
                         int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
                         int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev /* 2 per pass, or null */,
                         float *pass_ms /* accumulated, or null */, int gather_pass_only /* placement probe: stop after pass 1 */)
@@ -354,6 +378,64 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
     }
     return ZMLS_OK;
 }
+
+// Layout adapters (layout.hip, period_sum.hip) around run_passes for multi-pass plans:
+//   time-contiguous captures (a stack of single-channel arrays; also the reference's own (n,) and (n,1) inputs)
+//       -> periods summed and transposed into a frame-major staging array of sums, passes on that
+//   frame-major captures that cannot be read as 16-byte vectors (int16/int32/float32-into-f64, odd channel counts)
+//       -> periods summed (coalesced) into the same staging array
+//   time-contiguous responses -> passes write a frame-major staging array, transposed out.
+// Without staging (zmls_plan_reserve_staging) everything still works through the element path, slowly.
+int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
+                        int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
+                        int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms, int gather_pass_only)
+{
+    if (!p || !d_x || (!d_h && !gather_pass_only)) { set_error("null argument"); return ZMLS_E_ARG; }
+    const size_t is = dtype_size(in_dtype), ts = dtype_size(p->dtype);
+    if (!is) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
+    if (n_ch < 1) { set_error("need at least one channel"); return ZMLS_E_ARG; }
+    if (row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("strides must be positive"); return ZMLS_E_ARG; }
+    const int E = (int)(kVecBytes / ts);
+    const bool multi = p->npass > 1 && !gather_pass_only;
+    const bool vec_in = in_dtype == p->dtype && ch_stride == 1 && (row_stride * (int64_t)ts) % kVecBytes == 0 &&
+                        ((uintptr_t)d_x % kVecBytes) == 0 && n_ch % E == 0;
+    const bool vec_out = out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 && ((uintptr_t)d_h % kVecBytes) == 0 && n_ch % E == 0;
+    const int64_t per_ch = p->L * (int64_t)ts;                                    // staging bytes per channel
+    int64_t cc = (int64_t)(p->stage_bytes / (size_t)per_ch) / E * E;              // channels a staging array holds
+    const bool in_cm = multi && !vec_in && row_stride == 1 && cc >= E;
+    const bool in_fm = multi && !vec_in && !in_cm && ch_stride == 1 && cc >= E;
+    const bool out_cm = multi && !vec_out && out_row_stride == 1 && cc >= E;
+    if (!in_cm && !in_fm && !out_cm)
+        return run_passes(p, d_x, in_dtype, periods, skip_periods, divisor, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride,
+                          st, ev, pass_ms, gather_pass_only);
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    for (int64_t c0 = 0; c0 < n_ch; c0 += cc) {
+        const int64_t n = (n_ch - c0 < cc) ? n_ch - c0 : cc;
+        const int64_t Cs = (n + E - 1) / E * E;
+        const bool both = (in_cm || in_fm) && out_cm;
+        const int64_t n_pass = both ? Cs : n;                                     // pad columns ride along when both sides are staged
+        const void *src = (const char *)d_x + (size_t)(c0 * ch_stride) * is;
+        int src_dtype = in_dtype, src_skip = skip_periods;
+        int64_t src_periods = periods, src_rs = row_stride, src_cs = ch_stride;
+        if (in_cm || in_fm) {
+            if (in_cm) rc = launch_sum_transpose(d_x, in_dtype, p->dtype, p->L, periods, skip_periods, ch_stride, c0, n_ch, p->d_stage[0], Cs, st);
+            else rc = launch_period_sum(d_x, in_dtype, p->dtype, p->L, periods, skip_periods, row_stride, 1, 1, 0, c0, Cs, n_ch, p->d_stage[0], st);
+            if (rc) return rc;
+            src = p->d_stage[0]; src_dtype = p->dtype; src_skip = 0; src_periods = 1; src_rs = Cs; src_cs = 1;
+        }
+        void *dst = (char *)d_h + (size_t)(c0 * out_ch_stride) * ts;
+        int64_t dst_rs = out_row_stride, dst_cs = out_ch_stride;
+        if (out_cm) { dst = p->d_stage[1]; dst_rs = Cs; dst_cs = 1; }
+        rc = run_passes(p, src, src_dtype, src_periods, src_skip, divisor, n_pass, src_rs, src_cs, dst, dst_rs, dst_cs, st, ev, pass_ms, 0);
+        if (rc) return rc;
+        if (out_cm) {
+            rc = launch_transpose_out(p->d_stage[1], p->dtype, p->L, Cs, n, (char *)d_h + (size_t)(c0 * out_ch_stride) * ts, out_ch_stride, st);
+            if (rc) return rc;
+        }
+    }
+    return ZMLS_OK;
+}
 } // namespace zmls
 
 namespace {
@@ -417,6 +499,15 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
     if (rc) return rc;
     rc = zmls_plan_reserve(p, n_ch);
     if (rc) return rc;
+    {
+        // anything but 16-byte-aligned frame-major data of the plan's own type goes through the staging arrays
+        const int64_t E = (int64_t)(kVecBytes / ts);
+        const bool plain = in_dtype == p->dtype && ch_stride == 1 && out_ch_stride == 1 && n_ch % E == 0 && row_stride % E == 0 && out_row_stride % E == 0;
+        if (!plain) {
+            rc = zmls_plan_reserve_staging(p, n_ch);
+            if (rc) return rc;
+        }
+    }
     const size_t in_span = (size_t)((n_rows - 1) * row_stride + (n_ch - 1) * ch_stride + 1) * is;
     const size_t out_span = (size_t)((p->L - 1) * out_row_stride + (n_ch - 1) * out_ch_stride + 1) * ts;
     void *d_x = nullptr, *d_h = nullptr;

@@ -234,7 +234,7 @@ int zmls_period_sum_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t 
     int rc = use_device(p->device);
     if (rc) return rc;
     return launch_period_sum(d_x, in_dtype, p->dtype, p->L, n_rows / p->L - skip_periods, skip_periods, row_stride, ch_stride, n_blocks,
-                             block_ch_stride, ch_first, block_ch, d_out, (hipStream_t)stream);
+                             block_ch_stride, ch_first, block_ch, -1, d_out, (hipStream_t)stream);
 }
 
 int zmls_impulse_sums_device(zmls_plan *p, const void *d_s, int64_t total_periods, int64_t n_ch, int64_t row_stride, int64_t ch_stride,
@@ -277,7 +277,7 @@ int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d
         if (local_periods == 0) ZHIP(hipMemsetAsync(c->d_send[buf], 0, (size_t)c->n_ranks * p->L * cc * ts, st));
         else {
             int r = launch_period_sum(d_x, in_dtype, p->dtype, p->L, local_periods, skip_periods, row_stride, ch_stride, c->n_ranks, share,
-                                      k * c->chunk_ch, cc, c->d_send[buf], st);
+                                      k * c->chunk_ch, cc, -1, c->d_send[buf], st);
             if (r) return r;
         }
         ZHIP(hipEventRecord(c->e_sum[buf], st));

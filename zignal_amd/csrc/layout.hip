@@ -1,0 +1,160 @@
+// Layout adapters either side of the transform, for captures that are not in the (frames, channels)
+// vector layout the fused gather pass wants.
+//
+// The reference handles one channel per call, so a batch of its captures is naturally a STACK of
+// single-channel arrays: (C, R*L), time contiguous ("capture-major"). Gathering a permuted row from that
+// layout is one 8-byte element per channel at stride R*L: 13x slower than the frame-major path (measured,
+// N=20, 512 captures x 16 periods: 192 ms against 14.4 ms). So such captures take two coalesced steps:
+//   sum_transpose_kernel : periods added up in time order (trim_and_avgerage's sum, zignal/measure/mls.py:284-306;
+//                          every sample read once, 512 contiguous bytes per wave) and transposed through
+//                          LDS into a frame-major (L, C) array of sums
+//   -> the normal passes on that one period of sums (division by the period count fused into the gather)
+//   transpose_out_kernel : the (L, C) frame-major responses back to (C, L), if the caller wants that.
+// The bound of all three is HBM; the extra traffic is 2(+2) x L x C elements, against R_avg x L x C read.
+#include "zmls_internal.h"
+
+namespace zmls {
+namespace {
+
+template <typename T> struct LVec;
+template <> struct LVec<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int E = 2; };
+template <> struct LVec<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int E = 4; };
+
+constexpr int kTileRows = 64;       // frames per tile = lanes of a wave
+constexpr int kTileBytes = 256;     // bytes of adjacent channels per frame of a tile
+
+template <typename T, typename TIN>
+__global__ void __launch_bounds__(256) sum_transpose_kernel(const TIN *__restrict__ x, int64_t L, int periods, int skip, int64_t ch_stride,
+                                                            int64_t ch_first, int64_t n_ch_valid, T *__restrict__ S, int64_t Cs)
+{
+    using V = typename LVec<T>::type;
+    constexpr int E = LVec<T>::E;
+    constexpr int TC = kTileBytes / (int)sizeof(T);     // channels per tile
+    constexpr int CPW = TC / 4;                          // channels per wave
+    __shared__ T tile[kTileRows][TC + E];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j0 = (int64_t)blockIdx.x * kTileRows;
+    const int64_t cb = (int64_t)blockIdx.y * TC;         // first channel of the tile inside the staging array
+    const int64_t j = j0 + lane;
+
+    T acc[CPW];
+    const TIN *src[CPW];
+    bool ok[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int64_t ch = ch_first + cb + wave * CPW + i;
+        ok[i] = j < L && ch < n_ch_valid;
+        src[i] = x + (ok[i] ? ch : 0) * ch_stride + (int64_t)skip * L + (ok[i] ? j : 0);
+        acc[i] = (T)0;
+    }
+    for (int p = 0; p < periods; ++p) {
+        TIN t[CPW];
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) t[i] = src[i][(int64_t)p * L];
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) acc[i] += (T)t[i];     // period order, as numpy adds the rows
+    }
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) tile[lane][wave * CPW + i] = ok[i] ? acc[i] : (T)0;
+    __syncthreads();
+    constexpr int VPR = TC / E;                          // 16-byte vectors per tile row
+    constexpr int RPP = 256 / VPR;                       // rows per sweep of the workgroup
+    const int vv = threadIdx.x % VPR, r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int r = r0; r < kTileRows; r += RPP) {
+        if (j0 + r < L && cb + vv * E < Cs) {
+            V o;
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = tile[r][vv * E + e];
+            *(V *)(S + (j0 + r) * Cs + cb + vv * E) = o;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict__ H, int64_t L, int64_t Cs, int64_t n_ch, T *__restrict__ out,
+                                                            int64_t out_ch_stride)
+{
+    using V = typename LVec<T>::type;
+    constexpr int E = LVec<T>::E;
+    constexpr int TC = kTileBytes / (int)sizeof(T);
+    constexpr int CPW = TC / 4;
+    __shared__ T tile[kTileRows][TC + E];
+    const int64_t j0 = (int64_t)blockIdx.x * kTileRows;
+    const int64_t cb = (int64_t)blockIdx.y * TC;
+    constexpr int VPR = TC / E;
+    constexpr int RPP = 256 / VPR;
+    const int vv = threadIdx.x % VPR, r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int r = r0; r < kTileRows; r += RPP) {
+        V o = (V)(T)0;
+        if (j0 + r < L && cb + vv * E < Cs) o = *(const V *)(H + (j0 + r) * Cs + cb + vv * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) tile[r][vv * E + e] = o[e];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j = j0 + lane;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int64_t ch = cb + wave * CPW + i;
+        if (j < L && ch < n_ch) out[ch * out_ch_stride + j] = tile[lane][wave * CPW + i];
+    }
+}
+
+template <typename T, typename TIN>
+int launch_sum_transpose_t(const void *d_x, int64_t L, int64_t periods, int skip, int64_t ch_stride, int64_t ch_first, int64_t n_ch_valid,
+                           void *d_S, int64_t Cs, hipStream_t st)
+{
+    constexpr int TC = kTileBytes / (int)sizeof(T);
+    const dim3 grid((uint32_t)((L + kTileRows - 1) / kTileRows), (uint32_t)((Cs + TC - 1) / TC));
+    hipLaunchKernelGGL((sum_transpose_kernel<T, TIN>), grid, dim3(256), 0, st, (const TIN *)d_x, L, (int)periods, skip, ch_stride, ch_first,
+                       n_ch_valid, (T *)d_S, Cs);
+    ZHIP(hipGetLastError());
+    return ZMLS_OK;
+}
+
+template <typename T>
+int launch_sum_transpose_in(const void *d_x, int in_dtype, int64_t L, int64_t periods, int skip, int64_t ch_stride, int64_t ch_first,
+                            int64_t n_ch_valid, void *d_S, int64_t Cs, hipStream_t st)
+{
+    switch (in_dtype) {
+    case ZMLS_F64: return launch_sum_transpose_t<T, double>(d_x, L, periods, skip, ch_stride, ch_first, n_ch_valid, d_S, Cs, st);
+    case ZMLS_F32: return launch_sum_transpose_t<T, float>(d_x, L, periods, skip, ch_stride, ch_first, n_ch_valid, d_S, Cs, st);
+    case ZMLS_I16: return launch_sum_transpose_t<T, int16_t>(d_x, L, periods, skip, ch_stride, ch_first, n_ch_valid, d_S, Cs, st);
+    case ZMLS_I32: return launch_sum_transpose_t<T, int32_t>(d_x, L, periods, skip, ch_stride, ch_first, n_ch_valid, d_S, Cs, st);
+    default: set_error("bad dtype"); return ZMLS_E_ARG;
+    }
+}
+
+} // namespace
+
+// x: channel `ch` at d_x + ch*ch_stride, time contiguous. S: (L, Cs) frame-major sums of the plan's dtype for channels
+// ch_first .. ch_first+Cs-1 (columns beyond n_ch_valid are zero). Cs must be a multiple of the 16-byte vector.
+int launch_sum_transpose(const void *d_x, int in_dtype, int out_dtype, int64_t L, int64_t periods, int skip_periods, int64_t ch_stride,
+                         int64_t ch_first, int64_t n_ch_valid, void *d_S, int64_t Cs, hipStream_t st)
+{
+    if (periods < 1 || periods > 0x7FFFFFFF) { set_error("period count out of range"); return ZMLS_E_ARG; }
+    if (out_dtype == ZMLS_F64) return launch_sum_transpose_in<double>(d_x, in_dtype, L, periods, skip_periods, ch_stride, ch_first, n_ch_valid, d_S, Cs, st);
+    if (out_dtype == ZMLS_F32) return launch_sum_transpose_in<float>(d_x, in_dtype, L, periods, skip_periods, ch_stride, ch_first, n_ch_valid, d_S, Cs, st);
+    set_error("sums are f64 or f32");
+    return ZMLS_E_ARG;
+}
+
+// H: (L, Cs) frame-major of `dtype`; out: channel c (< n_ch) at d_out + c*out_ch_stride, time contiguous.
+int launch_transpose_out(const void *d_H, int dtype, int64_t L, int64_t Cs, int64_t n_ch, void *d_out, int64_t out_ch_stride, hipStream_t st)
+{
+    if (dtype == ZMLS_F64) {
+        constexpr int TC = kTileBytes / 8;
+        const dim3 grid((uint32_t)((L + kTileRows - 1) / kTileRows), (uint32_t)((n_ch + TC - 1) / TC));
+        hipLaunchKernelGGL(transpose_out_kernel<double>, grid, dim3(256), 0, st, (const double *)d_H, L, Cs, n_ch, (double *)d_out, out_ch_stride);
+    } else if (dtype == ZMLS_F32) {
+        constexpr int TC = kTileBytes / 4;
+        const dim3 grid((uint32_t)((L + kTileRows - 1) / kTileRows), (uint32_t)((n_ch + TC - 1) / TC));
+        hipLaunchKernelGGL(transpose_out_kernel<float>, grid, dim3(256), 0, st, (const float *)d_H, L, Cs, n_ch, (float *)d_out, out_ch_stride);
+    } else { set_error("responses are f64 or f32"); return ZMLS_E_ARG; }
+    ZHIP(hipGetLastError());
+    return ZMLS_OK;
+}
+
+} // namespace zmls

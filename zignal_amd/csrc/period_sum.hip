@@ -63,7 +63,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) period_sum_elem_kernel(const void *__restrict__ x, int in_dtype, int64_t L, int periods, int skip,
                                                               int64_t row_stride, int64_t ch_stride, int64_t n_blocks,
                                                               int64_t block_ch_stride, int64_t ch_first, int64_t block_ch,
-                                                              T *__restrict__ out)
+                                                              int64_t ch_limit, T *__restrict__ out)
 {
     const int64_t per_frame = n_blocks * block_ch;
     const int64_t total = L * per_frame;
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) period_sum_elem_kernel(const void *__rest
         const int64_t c = r - q * block_ch;
         const int64_t ch = q * block_ch_stride + ch_first + c;
         T acc = (T)0;
-        for (int p = 0; p < periods; ++p)
+        for (int p = 0; p < (ch < ch_limit ? periods : 0); ++p)
             acc += sum_load<T>(x, ((int64_t)(skip + p) * L + j) * row_stride + ch * ch_stride, in_dtype);
         out[(q * L + j) * block_ch + c] = acc;
     }
@@ -84,14 +84,16 @@ __global__ void __launch_bounds__(256) period_sum_elem_kernel(const void *__rest
 
 int launch_period_sum(const void *d_x, int in_dtype, int out_dtype, int64_t L, int64_t periods, int skip_periods,
                       int64_t row_stride, int64_t ch_stride, int64_t n_blocks, int64_t block_ch_stride, int64_t ch_first,
-                      int64_t block_ch, void *d_out, hipStream_t st)
+                      int64_t block_ch, int64_t ch_limit, void *d_out, hipStream_t st)
 {
+    const int64_t last = (n_blocks - 1) * block_ch_stride + ch_first + block_ch;     // one past the last channel touched
+    if (ch_limit < 0) ch_limit = last;
     if (out_dtype != ZMLS_F64 && out_dtype != ZMLS_F32) { set_error("period sums are f64 or f32"); return ZMLS_E_ARG; }
     if (periods < 1 || periods > 0x7FFFFFFF) { set_error("period count out of range"); return ZMLS_E_ARG; }
     const size_t ts = dtype_size(out_dtype);
     const int E = (int)(kVecBytes / ts);
     const int64_t total_elems = L * n_blocks * block_ch;
-    const bool vec = in_dtype == out_dtype && ch_stride == 1 && block_ch % E == 0 && ch_first % E == 0 && block_ch_stride % E == 0 &&
+    const bool vec = last <= ch_limit && in_dtype == out_dtype && ch_stride == 1 && block_ch % E == 0 && ch_first % E == 0 && block_ch_stride % E == 0 &&
                      (row_stride * (int64_t)ts) % kVecBytes == 0 && ((uintptr_t)d_x % kVecBytes) == 0 && ((uintptr_t)d_out % kVecBytes) == 0;
     const int64_t work = vec ? total_elems / E : total_elems;
     int64_t grid = (work + 255) / 256;
@@ -107,10 +109,10 @@ int launch_period_sum(const void *d_x, int in_dtype, int out_dtype, int64_t L, i
     } else {
         if (out_dtype == ZMLS_F64)
             hipLaunchKernelGGL(period_sum_elem_kernel<double>, dim3((uint32_t)grid), dim3(256), 0, st, d_x, in_dtype, L, (int)periods,
-                               skip_periods, row_stride, ch_stride, n_blocks, block_ch_stride, ch_first, block_ch, (double *)d_out);
+                               skip_periods, row_stride, ch_stride, n_blocks, block_ch_stride, ch_first, block_ch, ch_limit, (double *)d_out);
         else
             hipLaunchKernelGGL(period_sum_elem_kernel<float>, dim3((uint32_t)grid), dim3(256), 0, st, d_x, in_dtype, L, (int)periods,
-                               skip_periods, row_stride, ch_stride, n_blocks, block_ch_stride, ch_first, block_ch, (float *)d_out);
+                               skip_periods, row_stride, ch_stride, n_blocks, block_ch_stride, ch_first, block_ch, ch_limit, (float *)d_out);
     }
     ZHIP(hipGetLastError());
     return ZMLS_OK;

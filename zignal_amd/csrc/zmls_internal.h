@@ -110,7 +110,10 @@ int launch_average(const void *d_x, int in_dtype, int64_t L, int64_t periods, in
 void synth_system(int64_t L, int64_t channel, uint64_t seed, double *taps, int64_t *delay);
 int launch_period_sum(const void *d_x, int in_dtype, int out_dtype, int64_t L, int64_t periods, int skip_periods,
                       int64_t row_stride, int64_t ch_stride, int64_t n_blocks, int64_t block_ch_stride, int64_t ch_first,
-                      int64_t block_ch, void *d_out, hipStream_t st);
+                      int64_t block_ch, int64_t ch_limit /* channels at or beyond it read as zero; -1: none */, void *d_out, hipStream_t st);
+int launch_sum_transpose(const void *d_x, int in_dtype, int out_dtype, int64_t L, int64_t periods, int skip_periods, int64_t ch_stride,
+                         int64_t ch_first, int64_t n_ch_valid, void *d_S, int64_t Cs, hipStream_t st);
+int launch_transpose_out(const void *d_H, int dtype, int64_t L, int64_t Cs, int64_t n_ch, void *d_out, int64_t out_ch_stride, hipStream_t st);
 int launch_extract_channel(void *d_dst, const void *d_src, int dtype, int64_t n_rows, int64_t row_stride,
                            int64_t ch_stride, int64_t channel, hipStream_t st);
 
@@ -135,6 +138,8 @@ struct zmls_plan {
     zmls::JumpTables *d_jt;
     void *d_work;
     size_t work_bytes;
+    void *d_stage[2];             // frame-major staging (sums in, responses out) for captures in other layouts
+    size_t stage_bytes;           // each
     int force_cfg;                // -1: choose per call; else a tile configuration (tests, tuning)
     int swizzle;                  // XCD-aware block mapping on/off (tuning)
     int work_layout;              // 0: workspace slab-major, 1: row-major with slab-fastest block order in every pass

@@ -88,8 +88,12 @@ class Plan:
         """-1 auto, 0 small tile, 1 big tile (tests / tuning)"""
         L.check(L.lib().zmls_plan_force_tile(self._h, int(cfg)))
 
-    def reserve(self, n_ch):
+    def reserve(self, n_ch, staging=False):
+        """Workspace for n_ch channels per launch; staging=True also reserves the layout-adapter arrays for captures
+        that are not aligned (frames, channels) data of the plan's dtype (zmls_plan_reserve_staging)."""
         L.check(L.lib().zmls_plan_reserve(self._h, int(n_ch)))
+        if staging:
+            L.check(L.lib().zmls_plan_reserve_staging(self._h, int(n_ch)))
 
     def alloc_capture(self, n_rows, n_ch, dtype_code=None, tries=0):
         """DeviceBuffer for an (n_rows, n_ch) C-contiguous capture, placed where this plan's gather pass reads it
