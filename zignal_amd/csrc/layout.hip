@@ -25,7 +25,8 @@ constexpr int kTileBytes = 256;     // bytes of adjacent channels per frame of a
 
 template <typename T, typename TIN>
 __global__ void __launch_bounds__(256) sum_transpose_kernel(const TIN *__restrict__ x, int64_t L, int periods, int skip, int64_t ch_stride,
-                                                            int64_t ch_first, int64_t n_ch_valid, T *__restrict__ S, int64_t Cs)
+                                                            int64_t ch_first, int64_t n_ch_valid, T *__restrict__ S, int64_t Cs,
+                                                            uint32_t n_cblk)
 {
     using V = typename LVec<T>::type;
     constexpr int E = LVec<T>::E;
@@ -33,8 +34,9 @@ __global__ void __launch_bounds__(256) sum_transpose_kernel(const TIN *__restric
     constexpr int CPW = TC / 4;                          // channels per wave
     __shared__ T tile[kTileRows][TC + E];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t j0 = (int64_t)blockIdx.x * kTileRows;
-    const int64_t cb = (int64_t)blockIdx.y * TC;         // first channel of the tile inside the staging array
+    // consecutive workgroups are the channel blocks of one run of frames: together they write whole rows of S
+    const int64_t j0 = (int64_t)(blockIdx.x / n_cblk) * kTileRows;
+    const int64_t cb = (int64_t)(blockIdx.x % n_cblk) * TC;   // first channel of the tile inside the staging array
     const int64_t j = j0 + lane;
 
     T acc[CPW];
@@ -47,12 +49,21 @@ __global__ void __launch_bounds__(256) sum_transpose_kernel(const TIN *__restric
         src[i] = x + (ok[i] ? ch : 0) * ch_stride + (int64_t)skip * L + (ok[i] ? j : 0);
         acc[i] = (T)0;
     }
-    for (int p = 0; p < periods; ++p) {
-        TIN t[CPW];
+    int p = 0;
+    for (; p + 2 <= periods; p += 2) {                        // two periods of loads in flight per lane
+        TIN t[CPW], w[CPW];
 #pragma unroll
         for (int i = 0; i < CPW; ++i) t[i] = src[i][(int64_t)p * L];
 #pragma unroll
+        for (int i = 0; i < CPW; ++i) w[i] = src[i][(int64_t)(p + 1) * L];
+#pragma unroll
         for (int i = 0; i < CPW; ++i) acc[i] += (T)t[i];     // period order, as numpy adds the rows
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) acc[i] += (T)w[i];
+    }
+    if (p < periods) {
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) acc[i] += (T)src[i][(int64_t)p * L];
     }
 #pragma unroll
     for (int i = 0; i < CPW; ++i) tile[lane][wave * CPW + i] = ok[i] ? acc[i] : (T)0;
@@ -73,15 +84,15 @@ __global__ void __launch_bounds__(256) sum_transpose_kernel(const TIN *__restric
 
 template <typename T>
 __global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict__ H, int64_t L, int64_t Cs, int64_t n_ch, T *__restrict__ out,
-                                                            int64_t out_ch_stride)
+                                                            int64_t out_ch_stride, uint32_t n_cblk)
 {
     using V = typename LVec<T>::type;
     constexpr int E = LVec<T>::E;
     constexpr int TC = kTileBytes / (int)sizeof(T);
     constexpr int CPW = TC / 4;
     __shared__ T tile[kTileRows][TC + E];
-    const int64_t j0 = (int64_t)blockIdx.x * kTileRows;
-    const int64_t cb = (int64_t)blockIdx.y * TC;
+    const int64_t j0 = (int64_t)(blockIdx.x / n_cblk) * kTileRows;
+    const int64_t cb = (int64_t)(blockIdx.x % n_cblk) * TC;
     constexpr int VPR = TC / E;
     constexpr int RPP = 256 / VPR;
     const int vv = threadIdx.x % VPR, r0 = threadIdx.x / VPR;
@@ -107,9 +118,10 @@ int launch_sum_transpose_t(const void *d_x, int64_t L, int64_t periods, int skip
                            void *d_S, int64_t Cs, hipStream_t st)
 {
     constexpr int TC = kTileBytes / (int)sizeof(T);
-    const dim3 grid((uint32_t)((L + kTileRows - 1) / kTileRows), (uint32_t)((Cs + TC - 1) / TC));
-    hipLaunchKernelGGL((sum_transpose_kernel<T, TIN>), grid, dim3(256), 0, st, (const TIN *)d_x, L, (int)periods, skip, ch_stride, ch_first,
-                       n_ch_valid, (T *)d_S, Cs);
+    const uint64_t n_cblk = (uint64_t)((Cs + TC - 1) / TC), blocks = (uint64_t)((L + kTileRows - 1) / kTileRows) * n_cblk;
+    if (blocks > 0x7FFFFFFFull) { set_error("layout grid out of range"); return ZMLS_E_ARG; }
+    hipLaunchKernelGGL((sum_transpose_kernel<T, TIN>), dim3((uint32_t)blocks), dim3(256), 0, st, (const TIN *)d_x, L, (int)periods, skip, ch_stride,
+                       ch_first, n_ch_valid, (T *)d_S, Cs, (uint32_t)n_cblk);
     ZHIP(hipGetLastError());
     return ZMLS_OK;
 }
@@ -146,12 +158,16 @@ int launch_transpose_out(const void *d_H, int dtype, int64_t L, int64_t Cs, int6
 {
     if (dtype == ZMLS_F64) {
         constexpr int TC = kTileBytes / 8;
-        const dim3 grid((uint32_t)((L + kTileRows - 1) / kTileRows), (uint32_t)((n_ch + TC - 1) / TC));
-        hipLaunchKernelGGL(transpose_out_kernel<double>, grid, dim3(256), 0, st, (const double *)d_H, L, Cs, n_ch, (double *)d_out, out_ch_stride);
+        const uint64_t n_cblk = (uint64_t)((n_ch + TC - 1) / TC), blocks = (uint64_t)((L + kTileRows - 1) / kTileRows) * n_cblk;
+        if (blocks > 0x7FFFFFFFull) { set_error("layout grid out of range"); return ZMLS_E_ARG; }
+        hipLaunchKernelGGL(transpose_out_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, st, (const double *)d_H, L, Cs, n_ch, (double *)d_out,
+                           out_ch_stride, (uint32_t)n_cblk);
     } else if (dtype == ZMLS_F32) {
         constexpr int TC = kTileBytes / 4;
-        const dim3 grid((uint32_t)((L + kTileRows - 1) / kTileRows), (uint32_t)((n_ch + TC - 1) / TC));
-        hipLaunchKernelGGL(transpose_out_kernel<float>, grid, dim3(256), 0, st, (const float *)d_H, L, Cs, n_ch, (float *)d_out, out_ch_stride);
+        const uint64_t n_cblk = (uint64_t)((n_ch + TC - 1) / TC), blocks = (uint64_t)((L + kTileRows - 1) / kTileRows) * n_cblk;
+        if (blocks > 0x7FFFFFFFull) { set_error("layout grid out of range"); return ZMLS_E_ARG; }
+        hipLaunchKernelGGL(transpose_out_kernel<float>, dim3((uint32_t)blocks), dim3(256), 0, st, (const float *)d_H, L, Cs, n_ch, (float *)d_out,
+                           out_ch_stride, (uint32_t)n_cblk);
     } else { set_error("responses are f64 or f32"); return ZMLS_E_ARG; }
     ZHIP(hipGetLastError());
     return ZMLS_OK;
