@@ -170,6 +170,24 @@ int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d
                                        int64_t row_stride, int64_t ch_stride,
                                        void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
 
+/* ---- emphasis / de-emphasis: replaces Filter.filter_samples = scipy.signal.lfilter(B, A, x, axis=0)
+ * (zignal/filters/linearfilter.py:62-63) as MLS.apply_emphasis / apply_deemphasis use it (mls.py:393-407) on the
+ * whole stimulus / capture. Same transposed-direct-form-II arithmetic per sample, float64, zero initial state; the
+ * recurrence is cut into blocks whose start states are put together with powers of the state matrix (iir.hip).
+ * b, a: numerator / denominator as lfilter takes them (normalised by a[0] here); order max(nb, na)-1 <= 8. */
+typedef struct zmls_iir zmls_iir;
+int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, int na, int device);
+int zmls_iir_destroy(zmls_iir *f);
+/* scratch for signals of up to n_rows frames x n_ch channels (allocates; outside timed regions) */
+int zmls_iir_reserve(zmls_iir *f, int64_t n_rows, int64_t n_ch);
+/* y (float64, any strides; may be x itself when x is float64 with the same strides) = lfilter(b, a, x) along frames.
+ * Enqueues three kernels on hip_stream; never allocates or synchronises. */
+int zmls_iir_device(zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
+                    int64_t ch_stride, double *d_y, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
+/* host buffers: y is (n_rows, n_ch) C-contiguous float64; uploads, filters, downloads, synchronous */
+int zmls_iir_host(zmls_iir *f, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
+                  int64_t ch_stride, double *y);
+
 /* ---- synthetic captures for benchmarking/tests (no reference counterpart; the
  * shape follows examples/ex_mls.py:16-28: stimulus through a short filter with a
  * delay, plus noise). Channel c: 16-tap decaying FIR g_c, delay d_c =

@@ -209,17 +209,18 @@ def test_mls_and_mls_simple_classes_against_reference_goldens():
     assert np.array_equal(mls.samples, arrays["mls_raw"])
     assert str(mls) == g["str"]
     mls.apply_emphasis()
-    assert np.array_equal(mls.samples, arrays["mls_emph"])
+    # emphasis runs on the device: lfilter's recurrence cut into parallel blocks, equal to rounding (floating point: tolerance)
+    assert rel_err(mls.samples, arrays["mls_emph"]) <= TOL64
     y = np.roll(mls.samples, 100, axis=0) * 0.5
     z = mls.apply_deemphasis(y)
-    assert np.array_equal(z, arrays["mls_deemph"])
+    assert rel_err(z, arrays["mls_deemph"]) <= TOL64
     k = mls.get_impulse(z)
     assert list(k.samples.shape) == g["ir_shape"] and (k.fs, k.ch, k.nofsamples) == (g["ir_fs"], g["ir_ch"], g["ir_nofsamples"])
     assert rel_err(k.samples, arrays["mls_ir"]) <= TOL64
     s = meta["simple"]
     ms = MLS_simple(N=s["N"], fs=s["fs"], repeats=s["repeats"], device=0)
     assert repr(ms) == s["repr"] and str(ms) == s["str"]
-    assert np.array_equal(ms.samples, arrays["simple_samples"])
+    assert rel_err(ms.samples, arrays["simple_samples"]) <= TOL64
     ir = ms.get_impulse(ms.samples)
     assert rel_err(ir.samples, arrays["simple_ir"]) <= TOL64
     with pytest.raises(AssertionError):

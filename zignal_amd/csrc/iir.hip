@@ -1,0 +1,360 @@
+// Emphasis / de-emphasis on the device: a linear recursive filter along time, SURVEY.md §8(f) row 1.
+//
+// Reference: MLS.apply_emphasis / apply_deemphasis (zignal/measure/mls.py:393-407) call
+// Filter.filter_samples = scipy.signal.lfilter(B, A, x, axis=0) (zignal/filters/linearfilter.py:62-63) on the
+// whole (R*L, 1) stimulus / capture right before the hot path. lfilter runs the transposed direct form II
+//     y[n] = b0 x[n] + z0 ;  z_i = b_{i+1} x[n] + z_{i+1} - a_{i+1} y[n] ;  z_{S-1} = b_S x[n] - a_S y[n]
+// one sample after the other. The recurrence is linear in the state: z' = A z + B x, so it is cut into
+// sub-blocks that run in parallel from a zero state, and the true start state of every sub-block is put
+// together from the zero-state end states with powers of A:
+//   chunk kernel (pass 1): a workgroup loads a chunk (8192 samples: 256 sub-blocks of 32) into LDS with coalesced
+//       reads, every thread runs its sub-block from zero, an in-LDS scan with A^32, A^64, ... gives the chunk's
+//       zero-state end state;
+//   combine kernel: one thread per channel walks the chunks, s_{c+1} = A^chunk s_c + end_c;
+//   chunk kernel (pass 2): same load and scan, now with the chunk's start state, every thread reruns its sub-block
+//       from its true start state and the chunk is written back coalesced.
+// Same arithmetic per sample as lfilter (same operation order inside a sub-block); the start states differ from
+// the sequential ones by rounding only (~1e-16 relative for the stable filters MLS accepts: it asserts minimum
+// phase, mls.py:365-369). All arithmetic is float64, as lfilter's is for float64 coefficients.
+// Streaming: the signal is read twice and written once; integer VALU and LDS are far from limits; bound: HBM.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "zmls_internal.h"
+
+namespace zmls {
+
+constexpr int kIirSub = 32;        // samples per thread
+constexpr int kIirMaxS = 8;        // largest state size (filter order) built
+constexpr int kIirLevels = 9;      // P[d] = A^(32 * 2^d), d = 0..8
+constexpr int kIirPitch = kIirSub + 1;
+
+struct IirDev {
+    double b[kIirMaxS + 1], a[kIirMaxS + 1];       // normalised: a[0] = 1
+    double P[kIirLevels][kIirMaxS * kIirMaxS];     // row-major, row stride kIirMaxS
+};
+
+namespace {
+
+__device__ __forceinline__ double iir_load(const void *base, int64_t idx, int dtype)
+{
+    switch (dtype) {
+    case ZMLS_F64: return ((const double *)base)[idx];
+    case ZMLS_F32: return (double)((const float *)base)[idx];
+    case ZMLS_I16: return (double)((const int16_t *)base)[idx];
+    default: return (double)((const int32_t *)base)[idx];
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void matvec_acc(const double *__restrict__ M, const double (&u)[S], double (&v)[S])
+{
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        double s = v[i];
+#pragma unroll
+        for (int j = 0; j < S; ++j) s = __builtin_fma(M[i * kIirMaxS + j], u[j], s);
+        v[i] = s;
+    }
+}
+
+// one sample of lfilter's transposed direct form II, in its operation order
+template <int S>
+__device__ __forceinline__ double df2t_step(const IirDev *__restrict__ f, double x, double (&z)[S])
+{
+#pragma clang fp contract(off)      // separate multiplies and adds, as lfilter's compiled C has them
+    const double y = f->b[0] * x + z[0];
+#pragma unroll
+    for (int k = 0; k + 1 < S; ++k) z[k] = f->b[k + 1] * x + z[k + 1] - f->a[k + 1] * y;
+    z[S - 1] = f->b[S] * x - f->a[S] * y;
+    return y;
+}
+
+// CC = channels per chunk tile: 1 for time-contiguous signals (8192 frames x 1 channel), 16 for frame-major ones
+// (512 frames x 16 channels); either way a tile is 8192 samples and a thread owns 32 consecutive frames of one channel.
+template <int S, int CC, bool FINAL>
+__global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict__ f, const void *__restrict__ x, int in_dtype, int64_t n_rows,
+                                                        int64_t n_ch, int64_t rs, int64_t cs, uint32_t n_cgrp, double *__restrict__ zc,
+                                                        const double *__restrict__ sin, double *__restrict__ y, int64_t ors, int64_t ocs)
+{
+    constexpr int NB = 256 / CC;
+    constexpr int LOGNB = (CC == 1) ? 8 : 4;
+    constexpr int TT = NB * kIirSub;
+    static_assert(CC == 1 || CC == 16, "tile shapes built");
+    __shared__ double tile[256 * kIirPitch];
+    __shared__ double sc[256 * S];
+    const int tid = threadIdx.x;
+    const int64_t chunk = blockIdx.x / n_cgrp;
+    const int64_t t0 = chunk * TT, c0 = (int64_t)(blockIdx.x % n_cgrp) * CC;
+
+    for (int e = tid; e < TT * CC; e += 256) {
+        const int tt = e / CC, cc = e % CC;
+        const int64_t t = t0 + tt, c = c0 + cc;
+        const double v = (t < n_rows && c < n_ch) ? iir_load(x, t * rs + c * cs, in_dtype) : 0.0;
+        tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)] = v;
+    }
+    __syncthreads();
+
+    const int sb = tid / CC;                       // which 32-frame run of its channel this thread owns
+    const int64_t c = c0 + tid % CC;
+    double v[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) v[k] = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < kIirSub; ++i) (void)df2t_step<S>(f, tile[tid * kIirPitch + i], v);
+
+    // inclusive scan over the runs of one channel: v_k = sum_{i<=k} (A^32)^(k-i) end_i
+#pragma unroll
+    for (int d = 0; d < LOGNB; ++d) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) sc[tid * S + k] = v[k];
+        __syncthreads();
+        if (sb >= (1 << d)) {
+            double u[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) u[k] = sc[(tid - (CC << d)) * S + k];
+            matvec_acc<S>(f->P[d], u, v);
+        }
+        __syncthreads();
+    }
+    if constexpr (!FINAL) {
+        if (sb == NB - 1 && c < n_ch) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) zc[(chunk * n_ch + c) * S + k] = v[k];
+        }
+        return;
+    } else {
+#pragma unroll
+        for (int k = 0; k < S; ++k) sc[tid * S + k] = v[k];
+        __syncthreads();
+        double z[S], w[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            z[k] = sb > 0 ? sc[(tid - CC) * S + k] : 0.0;
+            w[k] = c < n_ch ? sin[(chunk * n_ch + c) * S + k] : 0.0;
+        }
+        // (A^32)^sb applied to the chunk's start state
+#pragma unroll
+        for (int d = 0; d < LOGNB; ++d) {
+            if ((sb >> d) & 1) {
+                double r[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) r[k] = 0.0;
+                matvec_acc<S>(f->P[d], w, r);
+#pragma unroll
+                for (int k = 0; k < S; ++k) w[k] = r[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) z[k] += w[k];
+#pragma unroll 4
+        for (int i = 0; i < kIirSub; ++i) tile[tid * kIirPitch + i] = df2t_step<S>(f, tile[tid * kIirPitch + i], z);
+        __syncthreads();
+        for (int e = tid; e < TT * CC; e += 256) {
+            const int tt = e / CC, cc = e % CC;
+            const int64_t t = t0 + tt, ch = c0 + cc;
+            if (t < n_rows && ch < n_ch) y[t * ors + ch * ocs] = tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)];
+        }
+    }
+}
+
+template <int S>
+__global__ void __launch_bounds__(64) iir_combine_kernel(const IirDev *__restrict__ f, int level, int64_t n_chunks, int64_t n_ch,
+                                                         const double *__restrict__ zc, double *__restrict__ sin)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ch) return;
+    double s[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) s[k] = 0.0;        // lfilter starts at rest
+    for (int64_t q = 0; q < n_chunks; ++q) {
+        double e[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            sin[(q * n_ch + c) * S + k] = s[k];
+            e[k] = zc[(q * n_ch + c) * S + k];
+        }
+        matvec_acc<S>(f->P[level], s, e);          // e = A^chunk s + end_q
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[k] = e[k];
+    }
+}
+
+template <int S, int CC>
+int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs, double *d_zc, double *d_sin,
+                 double *d_y, int64_t ors, int64_t ocs, hipStream_t st)
+{
+    constexpr int NB = 256 / CC, TT = NB * kIirSub, LOGNB = (CC == 1) ? 8 : 4;
+    const uint64_t n_cgrp = (uint64_t)((n_ch + CC - 1) / CC), n_chunks = (uint64_t)((n_rows + TT - 1) / TT);
+    const uint64_t blocks = n_cgrp * n_chunks;
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
+    hipLaunchKernelGGL((iir_chunk_kernel<S, CC, false>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, n_rows, n_ch, rs, cs,
+                       (uint32_t)n_cgrp, d_zc, (const double *)nullptr, (double *)nullptr, ors, ocs);
+    hipLaunchKernelGGL(iir_combine_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
+                       (const double *)d_zc, d_sin);
+    hipLaunchKernelGGL((iir_chunk_kernel<S, CC, true>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, n_rows, n_ch, rs, cs,
+                       (uint32_t)n_cgrp, (double *)nullptr, (const double *)d_sin, d_y, ors, ocs);
+    ZHIP(hipGetLastError());
+    return ZMLS_OK;
+}
+
+template <int S>
+int launch_iir_cc(bool time_contiguous, const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs,
+                  double *d_zc, double *d_sin, double *d_y, int64_t ors, int64_t ocs, hipStream_t st)
+{
+    if (time_contiguous) return launch_iir_s<S, 1>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_y, ors, ocs, st);
+    return launch_iir_s<S, 16>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_y, ors, ocs, st);
+}
+
+// A^k of the SxS state matrix by squaring, in long double
+void mat_mul(int S, const long double *X, const long double *Y, long double *Z)
+{
+    long double T[kIirMaxS * kIirMaxS];
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) {
+            long double s = 0;
+            for (int k = 0; k < S; ++k) s += X[i * S + k] * Y[k * S + j];
+            T[i * S + j] = s;
+        }
+    memcpy(Z, T, sizeof(long double) * S * S);
+}
+
+} // namespace
+} // namespace zmls
+
+struct zmls_iir {
+    int device;
+    int S;
+    zmls::IirDev *d_f;
+    double *d_zc, *d_sin;
+    size_t scratch_elems;      // each
+};
+
+using namespace zmls;
+
+extern "C" {
+
+int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, int na, int device)
+{
+    if (!out || !b || !a || nb < 1 || na < 1) { set_error("null or empty filter coefficients"); return ZMLS_E_ARG; }
+    *out = nullptr;
+    if (a[0] == 0.0 || !isfinite(a[0])) { set_error("a[0] must be a finite non-zero number"); return ZMLS_E_ARG; }
+    int S = (nb > na ? nb : na) - 1;
+    if (S > kIirMaxS) { set_error("filter order %d is beyond the %d built for the device", S, kIirMaxS); return ZMLS_E_UNSUPPORTED; }
+    if (S < 1) S = 1;           // a pure gain runs as a first-order filter with zero taps
+    int rc = use_device(device);
+    if (rc) return rc;
+    IirDev h;
+    memset(&h, 0, sizeof h);
+    for (int i = 0; i < nb; ++i) h.b[i] = b[i] / a[0];     // lfilter normalises by a[0]
+    for (int i = 0; i < na; ++i) h.a[i] = a[i] / a[0];
+    // state matrix of the transposed direct form II: z' = A z + (...) x with A[i][0] = -a[i+1], A[i][i+1] = 1
+    long double A[kIirMaxS * kIirMaxS] = {0}, Pw[kIirMaxS * kIirMaxS];
+    for (int i = 0; i < S; ++i) {
+        A[i * S + 0] = -(long double)h.a[i + 1];
+        if (i + 1 < S) A[i * S + i + 1] += 1.0L;
+    }
+    memcpy(Pw, A, sizeof(long double) * S * S);
+    for (int k = 0; k < 5; ++k) mat_mul(S, Pw, Pw, Pw);      // A^32
+    for (int d = 0; d < kIirLevels; ++d) {
+        for (int i = 0; i < S; ++i)
+            for (int j = 0; j < S; ++j) h.P[d][i * kIirMaxS + j] = (double)Pw[i * S + j];
+        mat_mul(S, Pw, Pw, Pw);
+    }
+    zmls_iir *f = (zmls_iir *)calloc(1, sizeof(zmls_iir));
+    if (!f) { set_error("out of host memory"); return ZMLS_E_ARG; }
+    f->device = device;
+    f->S = S;
+    hipError_t e = hipMalloc((void **)&f->d_f, sizeof(IirDev));
+    if (e == hipSuccess) e = hipMemcpy(f->d_f, &h, sizeof h, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        rc = hip_fail(e, "filter upload");
+        if (f->d_f) (void)hipFree(f->d_f);
+        free(f);
+        return rc;
+    }
+    *out = f;
+    return ZMLS_OK;
+}
+
+int zmls_iir_destroy(zmls_iir *f)
+{
+    if (!f) return ZMLS_OK;
+    if (hipSetDevice(f->device) == hipSuccess) {
+        if (f->d_f) (void)hipFree(f->d_f);
+        if (f->d_zc) (void)hipFree(f->d_zc);
+        if (f->d_sin) (void)hipFree(f->d_sin);
+    }
+    free(f);
+    return ZMLS_OK;
+}
+
+// chunk states for signals of up to n_rows frames x n_ch channels in either layout
+int zmls_iir_reserve(zmls_iir *f, int64_t n_rows, int64_t n_ch)
+{
+    if (!f || n_rows < 1 || n_ch < 1) { set_error("bad reserve arguments"); return ZMLS_E_ARG; }
+    int rc = use_device(f->device);
+    if (rc) return rc;
+    const int64_t tt = (256 / 16) * kIirSub;                                   // the shorter chunk (frame-major tiles)
+    const size_t need = (size_t)((n_rows + tt - 1) / tt) * (size_t)n_ch * (size_t)f->S;
+    if (need <= f->scratch_elems) return ZMLS_OK;
+    if (f->d_zc) { ZHIP(hipFree(f->d_zc)); f->d_zc = nullptr; }
+    if (f->d_sin) { ZHIP(hipFree(f->d_sin)); f->d_sin = nullptr; }
+    f->scratch_elems = 0;
+    ZHIP(hipMalloc((void **)&f->d_zc, need * 8));
+    ZHIP(hipMalloc((void **)&f->d_sin, need * 8));
+    f->scratch_elems = need;
+    return ZMLS_OK;
+}
+
+int zmls_iir_device(zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride, int64_t ch_stride,
+                    double *d_y, int64_t out_row_stride, int64_t out_ch_stride, void *stream)
+{
+    if (!f || !d_x || !d_y) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
+    if (n_rows < 1 || n_ch < 1 || row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
+    int rc = use_device(f->device);
+    if (rc) return rc;
+    const bool tc = row_stride == 1 && (n_ch == 1 || ch_stride != 1);
+    const int64_t tt = (256 / (tc ? 1 : 16)) * kIirSub;
+    const size_t need = (size_t)((n_rows + tt - 1) / tt) * (size_t)n_ch * (size_t)f->S;
+    if (need > f->scratch_elems) { set_error("filter scratch holds %zu chunk states, %zu needed: call zmls_iir_reserve first", f->scratch_elems, need); return ZMLS_E_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+#define ZIIR(SS) case SS: return launch_iir_cc<SS>(tc, f->d_f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, f->d_zc, f->d_sin, d_y, out_row_stride, out_ch_stride, st);
+    switch (f->S) {
+        ZIIR(1) ZIIR(2) ZIIR(3) ZIIR(4) ZIIR(5) ZIIR(6) ZIIR(7) ZIIR(8)
+    default: break;
+    }
+#undef ZIIR
+    set_error("no filter kernel for order %d", f->S);
+    return ZMLS_E_UNSUPPORTED;
+}
+
+int zmls_iir_host(zmls_iir *f, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride, int64_t ch_stride, double *y)
+{
+    if (!f || !x || !y) { set_error("null argument"); return ZMLS_E_ARG; }
+    const size_t is = dtype_size(in_dtype);
+    if (!is) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
+    if (n_rows < 1 || n_ch < 1 || row_stride < 1 || ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
+    int rc = zmls_iir_reserve(f, n_rows, n_ch);
+    if (rc) return rc;
+    const size_t in_span = (size_t)((n_rows - 1) * row_stride + (n_ch - 1) * ch_stride + 1) * is;
+    const size_t out_bytes = (size_t)n_rows * n_ch * 8;
+    void *d_x = nullptr;
+    double *d_y = nullptr;
+    hipError_t e = hipMalloc(&d_x, in_span);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_y, out_bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_x, x, in_span, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "filter staging");
+    // the result keeps the layout class of the input: (n_rows, n_ch) C-contiguous
+    if (!rc) rc = zmls_iir_device(f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_y, n_ch, 1, nullptr);
+    if (!rc) {
+        e = hipMemcpy(y, d_y, out_bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "filter download");
+    }
+    if (d_x) (void)hipFree(d_x);
+    if (d_y) (void)hipFree(d_y);
+    return rc;
+}
+
+} // extern "C"

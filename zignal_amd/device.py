@@ -181,6 +181,46 @@ class Plan:
         return np.array(list(taps)), d.value
 
 
+class IirFilter:
+    """lfilter(B, A, x, axis=0) on the GPU (zmls_iir_*): what MLS.apply_emphasis / apply_deemphasis run
+    (zignal/measure/mls.py:393-407, zignal/filters/linearfilter.py:62-63). Orders up to 8."""
+
+    MAX_ORDER = 8
+
+    def __init__(self, B, A, device=None):
+        self.device = L.default_device() if device is None else int(device)
+        b = np.ascontiguousarray(np.atleast_1d(B), dtype=np.float64)
+        a = np.ascontiguousarray(np.atleast_1d(A), dtype=np.float64)
+        h = ctypes.c_void_p()
+        L.check(L.lib().zmls_iir_create(ctypes.byref(h), b.ctypes.data, b.size, a.ctypes.data, a.size, self.device))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().zmls_iir_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def reserve(self, n_rows, n_ch):
+        L.check(L.lib().zmls_iir_reserve(self._h, int(n_rows), int(n_ch)))
+
+    def filter_host(self, x):
+        """x: (n,) or (n, C) ndarray -> float64 array of the same shape, filtered along axis 0."""
+        x2, code, n_rows, n_ch, rs, cs = Plan._as_capture(np.asarray(x))
+        y = np.empty((n_rows, n_ch), dtype=np.float64)
+        L.check(L.lib().zmls_iir_host(self._h, x2.ctypes.data, code, n_rows, n_ch, rs, cs, y.ctypes.data))
+        return y.reshape(np.shape(x))
+
+    def filter_device(self, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_y, out_row_stride, out_ch_stride, stream=None):
+        L.check(L.lib().zmls_iir_device(self._h, d_x, in_dtype, int(n_rows), int(n_ch), int(row_stride), int(ch_stride),
+                                        d_y, int(out_row_stride), int(out_ch_stride), stream))
+
+
 def sync(device=0):
     L.check(L.lib().zmls_dev_sync(device))
 

@@ -7,8 +7,8 @@ What runs where
     sequence bits, +1/-1 stimulus ........ HIP kernel (lfsr.hip), once per (N, taps) plan
     drop period 0 + average + circular
     cross-correlation + /L ............... HIP kernels (fwht_kernels.inc): gather -> FWHT -> scatter
-    emphasis / de-emphasis IIR ........... host, scipy.signal.lfilter (as the reference)
-There is no CPU implementation of the first two groups in this package.
+    emphasis / de-emphasis IIR ........... HIP kernels (iir.hip): lfilter's recurrence, block-parallel
+There is no CPU implementation of these in this package.
 """
 import logging
 import random
@@ -16,7 +16,8 @@ import random
 import numpy as np
 
 from ..audio import Audio
-from ..device import Plan
+from ..device import DeviceBuffer, IirFilter, Plan, sync
+from .. import _lib as _L
 from ..filters.biquads import RBJ
 from ..filters.linearfilter import Filter
 from .mlstaps import TAPS  # noqa: F401  (re-exported, as the reference does at mls.py:24)
@@ -165,6 +166,7 @@ class MLS(_MLS_base, Audio):
         self._length_impresp = self.L / self.fs
         self._filter_emphasis = Filter(B=B, A=A, fs=self.fs)
         self._filter_deemphasis = Filter(B=A, A=B, fs=self.fs)      # inverse filter
+        self._iirs = {}
 
         assert self._filter_emphasis.is_minimum_phase(), \
             "The emphasis filter must be minimum phase, i.e. possible to invert"
@@ -185,13 +187,48 @@ class MLS(_MLS_base, Audio):
         s += 'emphasis filt. A : %s\n' % str(A)
         return s
 
+    def _iir(self, which):
+        """Device filter for the emphasis ('e') or de-emphasis ('d') coefficients, built on first use."""
+        if which not in self._iirs:
+            B, A = (self._filter_emphasis if which == 'e' else self._filter_deemphasis).get_coefficients()
+            if max(len(B), len(A)) - 1 > IirFilter.MAX_ORDER:
+                raise NotImplementedError("emphasis filters beyond order %d are not built for the device" % IirFilter.MAX_ORDER)
+            self._iirs[which] = IirFilter(B, A, device=self._plan().device)
+        return self._iirs[which]
+
     def apply_emphasis(self):
-        """Filter the stimulus in place with the emphasis filter (mls.py:393-399)."""
-        self.samples = self._filter_emphasis.filter_samples(self.samples)
+        """Filter the stimulus in place with the emphasis filter (mls.py:393-399); lfilter's recurrence, on the
+        device."""
+        self.samples = self._iir('e').filter_host(self.samples)
 
     def apply_deemphasis(self, x):
-        """Filter a capture with the inverse of the emphasis filter (mls.py:401-407)."""
-        return self._filter_deemphasis.filter_samples(x)
+        """Filter a capture with the inverse of the emphasis filter (mls.py:401-407), on the device."""
+        return self._iir('d').filter_host(np.asarray(x))
+
+    def _get_impulse_deemphasised(self, x):
+        """apply_deemphasis followed by get_impulse without the capture leaving the GPU in between
+        (what MLS_simple.get_impulse does, mls.py:454-458): upload x, filter, transform, download the response."""
+        x = np.asarray(x)
+        assert len(x) > self.L, "The first sequence will be thrown away"
+        self._one_channel(x)
+        plan, iir = self._plan(), self._iir('d')
+        x2, code, n_rows, n_ch, rs, cs = Plan._as_capture(x)
+        d_x = DeviceBuffer(((n_rows - 1) * rs + (n_ch - 1) * cs + 1) * x2.itemsize, plan.device)
+        d_y = DeviceBuffer(n_rows * 8, plan.device)
+        d_h = DeviceBuffer(self.L * plan.np_dtype().itemsize, plan.device)
+        try:
+            _L.check(_L.lib().zmls_dev_upload(plan.device, d_x.ptr, x2.ctypes.data, d_x.nbytes))
+            iir.reserve(n_rows, 1)
+            plan.reserve(1, staging=True)
+            iir.filter_device(d_x.ptr, code, n_rows, 1, rs, cs, d_y.ptr, 1, 1)
+            plan.impulse_device(d_y.ptr, _L.ZMLS_F64, n_rows, 1, 1, 1, d_h.ptr, 1, 1)
+            sync(plan.device)
+            imp = d_h.download((self.L, 1), plan.np_dtype).astype(np.float64, copy=False)
+        finally:
+            d_x.free()
+            d_y.free()
+            d_h.free()
+        return Audio(fs=self.fs, initialdata=imp)
 
     def get_impulse(self, x):
         """Impulse response as an `Audio` (mls.py:409-414)."""
@@ -220,8 +257,7 @@ class MLS_simple(object):
         return s
 
     def get_impulse(self, x):
-        tmp = self._mls.apply_deemphasis(x)
-        self._impulseresponse = self._mls.get_impulse(tmp)
+        self._impulseresponse = self._mls._get_impulse_deemphasised(x)
         return self._impulseresponse
 
     def plot_fft(self, plotname=None):
