@@ -188,6 +188,22 @@ int zmls_iir_device(zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, 
 int zmls_iir_host(zmls_iir *f, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
                   int64_t ch_stride, double *y);
 
+/* ---- magnitude response: replaces Audio.fft (zignal/audio.py:678-704) as MLS_simple.plot_fft / examples/ex_mls.py:80
+ * call it on the recovered response: window, DFT of fftsize points (n_samples, or n_samples+1 for the Mersenne-prime
+ * sizes of audio.py:682-685), optional /fftsize, 20 log10 |Y|, bins 0..int(fftsize/2)-1. The DFT is hipFFT's
+ * (loaded on first use); float64. */
+typedef struct zmls_spectrum zmls_spectrum;
+int zmls_spectrum_create(zmls_spectrum **out, int64_t n_samples, int64_t n_ch, int device);
+int zmls_spectrum_destroy(zmls_spectrum *s);
+/* info[0]=n_samples info[1]=n_ch info[2]=fftsize info[3]=bins returned */
+int zmls_spectrum_info(const zmls_spectrum *s, int64_t info[4]);
+/* d_h: (n_samples, n_ch) float64 with the given strides; d_window: n_samples float64 or null (rectangular);
+ * d_mag: (bins, n_ch) C-contiguous float64, in dB. Enqueues on hip_stream; never allocates. */
+int zmls_spectrum_device(zmls_spectrum *s, const double *d_h, int64_t row_stride, int64_t ch_stride,
+                         const double *d_window, int normalise, double *d_mag, void *hip_stream);
+/* host buffers: h (n_samples, n_ch) C-contiguous, window n_samples or null, mag (bins, n_ch); synchronous */
+int zmls_spectrum_host(zmls_spectrum *s, const double *h, const double *window, int normalise, double *mag);
+
 /* ---- synthetic captures for benchmarking/tests (no reference counterpart; the
  * shape follows examples/ex_mls.py:16-28: stimulus through a short filter with a
  * delay, plus noise). Channel c: 16-tap decaying FIR g_c, delay d_c =

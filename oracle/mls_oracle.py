@@ -127,3 +127,25 @@ def xcorr_by_definition(avg, ref):
     for m in range(L):
         out[m] = np.dot(r, np.roll(a, -m)) / L
     return out.reshape(-1, 1)
+
+
+# ---------------------------------------------------------------------------
+# Next to the path: magnitude response of the recovered impulse response
+# ---------------------------------------------------------------------------
+def audio_fft(samples, fs, window='hann', normalise=True):
+    """`Audio.fft` (zignal/audio.py:678-704): window of nofsamples points, FFT of fftsize points (one more than
+    nofsamples when that is one of the listed Mersenne primes), optional /fftsize, 20 log10 |Y|, and the first
+    int(fftsize/2) bins and frequencies. Pinned by the N=13 / N=10 spectra in tests/golden/ (api.npz)."""
+    import scipy.signal.windows
+    nofsamples = samples.shape[0]
+    fftsize = nofsamples
+    if fftsize in [(2**13) - 1, (2**17) - 1, (2**19) - 1, (2**31) - 1]:
+        fftsize = fftsize + 1
+    win = np.expand_dims(scipy.signal.windows.get_window(window, Nx=nofsamples), axis=1)
+    Y = np.fft.fft(samples * win, n=fftsize, axis=0)
+    if normalise:
+        Y = Y / fftsize
+    with np.errstate(divide='ignore'):
+        mag = 20 * np.log10(np.abs(Y))
+    frq = np.fft.fftfreq(fftsize, 1 / fs)
+    return frq[:int(fftsize / 2)], mag[:int(fftsize / 2)]

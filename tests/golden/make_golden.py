@@ -265,12 +265,32 @@ def dump_api():
     write_json("api.json", meta)
 
 
+def dump_fft():
+    """Audio.fft (audio.py:678-704) on decaying-noise 'impulse responses': an ordinary size, a Mersenne-prime size
+    (fftsize bumped by one), the MLS use (rectangular, not normalised) and the default (hann, normalised)."""
+    arrays, cases = {}, []
+    for cid, (n, ch, fs, window, normalise, seed) in enumerate([
+            (1023, 1, 48000, "rectangular", False, 1), (1023, 2, 48000, "hann", True, 2),
+            (8191, 1, 96000, "rectangular", False, 3), (8191, 2, 44100, "hamming", True, 4),
+            (4095, 3, 48000, "rectangular", True, 5)]):
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal((n, ch)) * np.exp(-np.arange(n) / (n / 8.0))[:, None]
+        a = zignal.Audio(fs=fs, initialdata=x)
+        frq, mag = a.fft(window=window, normalise=normalise)
+        key = "c%d" % cid
+        arrays[key + "_frq"], arrays[key + "_mag"] = frq, mag
+        cases.append({"id": key, "n": n, "ch": ch, "fs": fs, "window": window, "normalise": normalise, "seed": seed,
+                      "bins": int(mag.shape[0]), "x_sha256": inputs.digest(x)})
+    np.savez_compressed(os.path.join(HERE, "fft.npz"), **arrays)
+    write_json("fft.json", {"cases": cases})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    steps = {"taps": dump_taps, "errors": dump_errors, "api": dump_api,
+    steps = {"taps": dump_taps, "errors": dump_errors, "api": dump_api, "fft": dump_fft,
              "seq": lambda: dump_seq_kats(a.quick), "ir": lambda: dump_ir(a.quick)}
     for name, fn in steps.items():
         if a.only and name not in a.only.split(","):

@@ -1,0 +1,67 @@
+"""GPU parity for the magnitude response: zmls_spectrum_* / Audio.fft against spectra
+captured from the reference's Audio.fft (tests/golden/fft.npz) and against the oracle's restatement on larger sizes.
+Floating point: linear magnitudes within 1e-12 x the largest bin (dB values of near-empty bins are ill-conditioned,
+so dB is compared where the bin holds at least 1e-6 of the peak: there 1e-12 linear is < 1e-5 dB)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import inputs
+from gpu_common import G
+from oracle import mls_oracle
+from zignal_amd.audio import Audio
+from zignal_amd.device import Spectrum
+from zignal_amd.measure.mls import MLS_simple
+
+pytestmark = pytest.mark.gpu
+
+
+def lin(db):
+    return np.power(10.0, db / 20.0)
+
+
+def check(mag, want):
+    assert mag.shape == want.shape
+    peak = np.max(lin(want))
+    assert np.max(np.abs(lin(mag) - lin(want))) <= 1e-12 * peak
+    strong = lin(want) >= 1e-6 * peak
+    assert np.max(np.abs(mag[strong] - want[strong])) <= 1e-5
+
+
+def test_audio_fft_against_reference_spectra():
+    meta = json.load(open(os.path.join(G, "fft.json")))
+    arrays = np.load(os.path.join(G, "fft.npz"))
+    for c in meta["cases"]:
+        rng = np.random.default_rng(c["seed"])
+        x = rng.standard_normal((c["n"], c["ch"])) * np.exp(-np.arange(c["n"]) / (c["n"] / 8.0))[:, None]
+        assert inputs.digest(x) == c["x_sha256"]
+        frq, mag = Audio(fs=c["fs"], initialdata=x).fft(window=c["window"], normalise=c["normalise"], device=0)
+        assert np.array_equal(frq, arrays[c["id"] + "_frq"])
+        check(mag, arrays[c["id"] + "_mag"])
+
+
+@pytest.mark.parametrize("N,ch", [(16, 1), (17, 2), (19, 1), (20, 1), (18, 5)])
+def test_mls_sized_responses_against_the_oracle(N, ch):
+    """L = 2^N - 1 points (odd, composite or Mersenne prime: N = 17, 19 get the size bump), rectangular window,
+    not normalised: exactly what MLS_simple.plot_fft asks for (mls.py:466)."""
+    L = (1 << N) - 1
+    rng = np.random.default_rng(N)
+    h = rng.standard_normal((L, ch)) * np.exp(-np.arange(L) / 3000.0)[:, None]
+    sp = Spectrum(L, ch, device=0)
+    assert sp.fftsize == L + (1 if N in (13, 17, 19, 31) else 0) and sp.n_bins == sp.fftsize // 2
+    _, want = mls_oracle.audio_fft(h, 96000, "rectangular", False)
+    check(sp.magnitude_db_host(h, None, False), want)
+    _, want = mls_oracle.audio_fft(h, 96000, "hann", True)
+    import scipy.signal.windows
+    check(sp.magnitude_db_host(h, scipy.signal.windows.get_window("hann", Nx=L), True), want)
+    sp.close()
+
+
+def test_mls_simple_response_spectrum_is_the_emphasis_free_flat_line():
+    ms = MLS_simple(N=12, fs=48000, repeats=3, device=0)
+    k = ms.get_impulse(ms.samples)                # loop-back: a unit impulse (minus 1/L)
+    frq, mag = k.fft(window='rectangular', normalise=False, device=0)
+    assert frq.shape == (mag.shape[0],) and mag.shape == ((ms._mls.L) // 2, 1)
+    assert np.max(np.abs(mag[1:])) < 1e-2         # flat 0 dB away from DC

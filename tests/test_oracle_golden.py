@@ -144,3 +144,18 @@ def test_oracle_error_table():
         table["impulse_two_channels"]["type"]
     assert name(lambda: mls_oracle.get_impulse(N, taps, list(good[:, 0]))) == table["impulse_list"]["type"]
     assert name(lambda: mls_oracle.get_impulse(N, taps, good)) is None
+
+
+def test_audio_fft_restatement_against_reference_spectra():
+    """oracle.audio_fft vs spectra captured from the reference's Audio.fft (tests/golden/make_golden.py: dump_fft),
+    including the Mersenne-prime size bump. Same numpy/scipy routines, so bit-for-bit."""
+    meta = json.load(open(os.path.join(G, "fft.json")))
+    arrays = np.load(os.path.join(G, "fft.npz"))
+    for c in meta["cases"]:
+        rng = np.random.default_rng(c["seed"])
+        x = rng.standard_normal((c["n"], c["ch"])) * np.exp(-np.arange(c["n"]) / (c["n"] / 8.0))[:, None]
+        assert inputs.digest(x) == c["x_sha256"]
+        frq, mag = mls_oracle.audio_fft(x, c["fs"], c["window"], c["normalise"])
+        assert mag.shape == (c["bins"], c["ch"])
+        assert np.array_equal(frq, arrays[c["id"] + "_frq"])
+        assert np.allclose(mag, arrays[c["id"] + "_mag"], rtol=0, atol=1e-9)

@@ -59,6 +59,11 @@ SIGNATURES = {
     "zmls_iir_reserve": [c_vp, c_i64, c_i64],
     "zmls_iir_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],
     "zmls_iir_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp],
+    "zmls_spectrum_create": [_vpp, c_i64, c_i64, c_int],
+    "zmls_spectrum_destroy": [c_vp],
+    "zmls_spectrum_info": [c_vp, ctypes.POINTER(c_i64)],
+    "zmls_spectrum_device": [c_vp, c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_vp],
+    "zmls_spectrum_host": [c_vp, c_vp, c_vp, c_int, c_vp],
     "zmls_synth_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_u64, ctypes.c_double, c_vp],
     "zmls_synth_system": [c_vp, c_i64, c_u64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)],
     "zmls_dev_alloc": [c_int, _vpp, c_sz],

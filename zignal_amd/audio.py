@@ -97,14 +97,26 @@ class Audio(object):
         rows.append('-----------------:---------------------')
         return "\n".join(rows) + "\n"
 
+    def fft(self, window='hann', normalise=True, device=None):
+        """FFT magnitude of all channels in dB, up to fs/2: (frq, mag) as zignal/audio.py:678-704. The transform
+        runs on the GPU (zmls_spectrum_*: window, hipFFT, dB); window values and the frequency axis are host work."""
+        import scipy.signal.windows
+        from .device import Spectrum
+        sp = Spectrum(self.nofsamples, self.ch, device=device)
+        try:
+            rect = window in ('rectangular', 'boxcar', 'box', 'ones', 'rect')
+            win = None if rect else scipy.signal.windows.get_window(window, Nx=self.nofsamples)   # not fftsize! (audio.py:690)
+            mag = sp.magnitude_db_host(self.samples, win, normalise)
+            frq = np.fft.fftfreq(sp.fftsize, 1 / self.fs)[:int(sp.fftsize / 2)]
+        finally:
+            sp.close()
+        return frq, mag
+
     def plot_fft(self, plotname=None, window='hamming', normalise=True, **kwargs):
-        """Magnitude response plot (audio.py:649-676). Plotting is outside this library's scope:
-        only the rectangular, un-normalised case MLS uses is offered, through matplotlib if present."""
-        if window != 'rectangular' or normalise:
-            raise NotImplementedError("zignal_amd.Audio.plot_fft only does window='rectangular', normalise=False")
+        """Magnitude response plot (audio.py:649-676): the spectrum comes from `fft` (GPU); drawing it is
+        matplotlib's job and outside this library's scope beyond this minimal figure."""
         import matplotlib.pyplot as plt
-        mag = 20 * np.log10(np.abs(np.fft.rfft(self.samples, axis=0)) + 1e-300)
-        freq = np.fft.rfftfreq(self.nofsamples, 1.0 / self.fs)
+        freq, mag = self.fft(window=window, normalise=normalise)
         plt.figure()
         plt.semilogx(freq[1:], mag[1:])
         plt.xlabel('Frequency [Hz]')

@@ -1,0 +1,206 @@
+// Magnitude response of an impulse response on the device — SURVEY.md §8(f) row 2.
+//
+// Reference: Audio.fft (zignal/audio.py:678-704) as MLS_simple.plot_fft / ex_mls.py:80 use it on the recovered
+// response: window the L samples, np.fft.fft with n = fftsize (L, or L+1 when L is one of the Mersenne primes
+// 2^13-1, 2^17-1, 2^19-1, 2^31-1, audio.py:682-685), optionally divide by fftsize, 20 log10 |Y|, keep bins
+// 0 .. int(fftsize/2)-1. Only the spectrum (half the response's size) then has to cross PCIe.
+//
+// The DFT itself is a plain library transform: hipFFT (double real-to-complex, one contiguous transform per
+// channel), loaded on first use. Around it two streaming kernels: window + zero-pad + transpose into
+// channel-major staging, and |Y| -> dB back into (bins, channels).
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
+#include <hipfft/hipfft.h>
+#include "zmls_internal.h"
+
+namespace zmls {
+namespace {
+
+struct HipFft {
+    void *handle = nullptr;
+    hipfftResult (*PlanMany)(hipfftHandle *, int, int *, int *, int, int, int *, int, int, hipfftType, int) = nullptr;
+    hipfftResult (*SetStream)(hipfftHandle, hipStream_t) = nullptr;
+    hipfftResult (*ExecD2Z)(hipfftHandle, hipfftDoubleReal *, hipfftDoubleComplex *) = nullptr;
+    hipfftResult (*Destroy)(hipfftHandle) = nullptr;
+    char why[256] = "";
+    bool ok = false;
+    HipFft()
+    {
+        const char *names[] = {"libhipfft.so.0", "libhipfft.so", "/opt/rocm/lib/libhipfft.so.0"};
+        for (const char *n : names) {
+            handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        if (!handle) { snprintf(why, sizeof why, "cannot load libhipfft: %s", dlerror()); return; }
+#define ZSYM(field, name)                                                                      \
+    field = (decltype(field))dlsym(handle, name);                                              \
+    if (!field) { snprintf(why, sizeof why, "libhipfft has no symbol %s", name); return; }
+        ZSYM(PlanMany, "hipfftPlanMany")
+        ZSYM(SetStream, "hipfftSetStream")
+        ZSYM(ExecD2Z, "hipfftExecD2Z")
+        ZSYM(Destroy, "hipfftDestroy")
+#undef ZSYM
+        ok = true;
+    }
+};
+
+HipFft *hipfft()
+{
+    static HipFft f;
+    if (!f.ok) { set_error("%s", f.why); return nullptr; }
+    return &f;
+}
+
+// stage[c][t] = h[t][c] * window[t] for t < n, 0 for n <= t < fftsize
+__global__ void __launch_bounds__(256) spectrum_prepare_kernel(const double *__restrict__ h, int64_t n, int64_t n_ch, int64_t row_stride,
+                                                               int64_t ch_stride, const double *__restrict__ window, int64_t fftsize,
+                                                               double *__restrict__ stage)
+{
+    const int64_t total = fftsize * n_ch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = idx / fftsize, t = idx - c * fftsize;
+        double v = 0.0;
+        if (t < n) {
+            v = h[t * row_stride + c * ch_stride];
+            if (window) v *= window[t];
+        }
+        stage[idx] = v;
+    }
+}
+
+// mag[k][c] = 20 log10(|Y[c][k]| * scale), k < n_bins
+__global__ void __launch_bounds__(256) spectrum_db_kernel(const double2 *__restrict__ Y, int64_t n_cplx, int64_t n_bins, int64_t n_ch, double scale,
+                                                          double *__restrict__ mag)
+{
+    const int64_t total = n_bins * n_ch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = idx / n_bins, k = idx - c * n_bins;
+        const double2 y = Y[c * n_cplx + k];
+        mag[k * n_ch + c] = 20.0 * log10(hypot(y.x, y.y) * scale);
+    }
+}
+
+bool mersenne_prime_size(int64_t n)
+{
+    return n == ((int64_t)1 << 13) - 1 || n == ((int64_t)1 << 17) - 1 || n == ((int64_t)1 << 19) - 1 || n == ((int64_t)1 << 31) - 1;
+}
+
+} // namespace
+} // namespace zmls
+
+struct zmls_spectrum {
+    int device;
+    int64_t n, n_ch, fftsize, n_bins, n_cplx;
+    hipfftHandle plan;
+    double *d_stage;        // (n_ch, fftsize)
+    double2 *d_Y;           // (n_ch, fftsize/2 + 1)
+};
+
+using namespace zmls;
+
+extern "C" {
+
+int zmls_spectrum_create(zmls_spectrum **out, int64_t n_samples, int64_t n_ch, int device)
+{
+    if (!out) { set_error("null argument"); return ZMLS_E_ARG; }
+    *out = nullptr;
+    if (n_samples < 2 || n_ch < 1 || n_samples >= ((int64_t)1 << 31) - 1) { set_error("bad spectrum size"); return ZMLS_E_ARG; }
+    int rc = use_device(device);
+    if (rc) return rc;
+    HipFft *F = hipfft();
+    if (!F) return ZMLS_E_UNSUPPORTED;
+    zmls_spectrum *s = (zmls_spectrum *)calloc(1, sizeof(zmls_spectrum));
+    if (!s) { set_error("out of host memory"); return ZMLS_E_ARG; }
+    s->device = device;
+    s->n = n_samples; s->n_ch = n_ch;
+    s->fftsize = n_samples + (mersenne_prime_size(n_samples) ? 1 : 0);      // audio.py:682-685
+    s->n_bins = s->fftsize / 2;                                             // int(fftsize/2), audio.py:701-702
+    s->n_cplx = s->fftsize / 2 + 1;
+    hipError_t e = hipMalloc((void **)&s->d_stage, (size_t)s->fftsize * n_ch * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_Y, (size_t)s->n_cplx * n_ch * 16);
+    if (e != hipSuccess) {
+        rc = hip_fail(e, "spectrum buffers");
+        (void)zmls_spectrum_destroy(s);
+        return rc;
+    }
+    int len[1] = {(int)s->fftsize};
+    hipfftResult r = F->PlanMany(&s->plan, 1, len, nullptr, 1, (int)s->fftsize, nullptr, 1, (int)s->n_cplx, HIPFFT_D2Z, (int)n_ch);
+    if (r != HIPFFT_SUCCESS) {
+        set_error("hipfftPlanMany(%lld points x %lld) failed with %d", (long long)s->fftsize, (long long)n_ch, (int)r);
+        s->plan = 0;
+        (void)zmls_spectrum_destroy(s);
+        return ZMLS_E_HIP;
+    }
+    *out = s;
+    return ZMLS_OK;
+}
+
+int zmls_spectrum_destroy(zmls_spectrum *s)
+{
+    if (!s) return ZMLS_OK;
+    if (hipSetDevice(s->device) == hipSuccess) {
+        HipFft *F = hipfft();
+        if (F && s->plan) (void)F->Destroy(s->plan);
+        if (s->d_stage) (void)hipFree(s->d_stage);
+        if (s->d_Y) (void)hipFree(s->d_Y);
+    }
+    free(s);
+    return ZMLS_OK;
+}
+
+int zmls_spectrum_info(const zmls_spectrum *s, int64_t info[4])
+{
+    if (!s || !info) { set_error("null argument"); return ZMLS_E_ARG; }
+    info[0] = s->n; info[1] = s->n_ch; info[2] = s->fftsize; info[3] = s->n_bins;
+    return ZMLS_OK;
+}
+
+int zmls_spectrum_device(zmls_spectrum *s, const double *d_h, int64_t row_stride, int64_t ch_stride, const double *d_window, int normalise,
+                         double *d_mag, void *stream)
+{
+    if (!s || !d_h || !d_mag) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (row_stride < 1 || ch_stride < 1) { set_error("strides must be positive"); return ZMLS_E_ARG; }
+    int rc = use_device(s->device);
+    if (rc) return rc;
+    HipFft *F = hipfft();
+    if (!F) return ZMLS_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    auto grid = [](int64_t n) { int64_t g = (n + 255) / 256; return (uint32_t)(g < 1 ? 1 : g > 65536 ? 65536 : g); };
+    hipLaunchKernelGGL(spectrum_prepare_kernel, dim3(grid(s->fftsize * s->n_ch)), dim3(256), 0, st, d_h, s->n, s->n_ch, row_stride, ch_stride,
+                       d_window, s->fftsize, s->d_stage);
+    ZHIP(hipGetLastError());
+    hipfftResult r = F->SetStream(s->plan, st);
+    if (r == HIPFFT_SUCCESS) r = F->ExecD2Z(s->plan, s->d_stage, (hipfftDoubleComplex *)s->d_Y);
+    if (r != HIPFFT_SUCCESS) { set_error("hipfftExecD2Z failed with %d", (int)r); return ZMLS_E_HIP; }
+    hipLaunchKernelGGL(spectrum_db_kernel, dim3(grid(s->n_bins * s->n_ch)), dim3(256), 0, st, s->d_Y, s->n_cplx, s->n_bins, s->n_ch,
+                       normalise ? 1.0 / (double)s->fftsize : 1.0, d_mag);
+    ZHIP(hipGetLastError());
+    return ZMLS_OK;
+}
+
+int zmls_spectrum_host(zmls_spectrum *s, const double *h, const double *window, int normalise, double *mag)
+{
+    if (!s || !h || !mag) { set_error("null argument"); return ZMLS_E_ARG; }
+    int rc = use_device(s->device);
+    if (rc) return rc;
+    double *d_h = nullptr, *d_w = nullptr, *d_m = nullptr;
+    const size_t hb = (size_t)s->n * s->n_ch * 8, mb = (size_t)s->n_bins * s->n_ch * 8;
+    hipError_t e = hipMalloc((void **)&d_h, hb);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_m, mb);
+    if (e == hipSuccess && window) e = hipMalloc((void **)&d_w, (size_t)s->n * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_h, h, hb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && window) e = hipMemcpy(d_w, window, (size_t)s->n * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "spectrum staging");
+    if (!rc) rc = zmls_spectrum_device(s, d_h, s->n_ch, 1, d_w, normalise, d_m, nullptr);
+    if (!rc) {
+        e = hipMemcpy(mag, d_m, mb, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "spectrum download");
+    }
+    if (d_h) (void)hipFree(d_h);
+    if (d_w) (void)hipFree(d_w);
+    if (d_m) (void)hipFree(d_m);
+    return rc;
+}
+
+} // extern "C"

@@ -221,6 +221,43 @@ class IirFilter:
                                         d_y, int(out_row_stride), int(out_ch_stride), stream))
 
 
+class Spectrum:
+    """Audio.fft on the GPU (zignal/audio.py:678-704): dB magnitude of (n_samples, n_ch) float64 data, bins
+    0..int(fftsize/2)-1, with the reference's Mersenne-prime size bump."""
+
+    def __init__(self, n_samples, n_ch=1, device=None):
+        self.device = L.default_device() if device is None else int(device)
+        h = ctypes.c_void_p()
+        L.check(L.lib().zmls_spectrum_create(ctypes.byref(h), int(n_samples), int(n_ch), self.device))
+        self._h = h
+        info = (ctypes.c_int64 * 4)()
+        L.check(L.lib().zmls_spectrum_info(self._h, info))
+        self.n_samples, self.n_ch, self.fftsize, self.n_bins = list(info)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().zmls_spectrum_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def magnitude_db_host(self, samples, window=None, normalise=True):
+        """samples: (n_samples, n_ch); window: n_samples values or None (rectangular) -> (bins, n_ch) dB"""
+        x = np.ascontiguousarray(samples, dtype=np.float64).reshape(self.n_samples, self.n_ch)
+        w = None if window is None else np.ascontiguousarray(window, dtype=np.float64).reshape(self.n_samples)
+        mag = np.empty((self.n_bins, self.n_ch), dtype=np.float64)
+        L.check(L.lib().zmls_spectrum_host(self._h, x.ctypes.data, None if w is None else w.ctypes.data, int(bool(normalise)),
+                                           mag.ctypes.data))
+        return mag
+
+    def magnitude_db_device(self, d_h, row_stride, ch_stride, d_window, normalise, d_mag, stream=None):
+        L.check(L.lib().zmls_spectrum_device(self._h, d_h, int(row_stride), int(ch_stride), d_window, int(bool(normalise)), d_mag, stream))
+
+
 def sync(device=0):
     L.check(L.lib().zmls_dev_sync(device))
 
