@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Device-time of the kernels either side of the headline path (HIP events, inputs resident): emphasis filter,
+magnitude response, layout adapters. Prints algorithmic GB/s (bytes each step must read + write once)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zignal_amd import _lib
+from zignal_amd.device import DeviceBuffer, IirFilter, Plan, Spectrum, Timer, sync
+from zignal_amd.filters.biquads import RBJ
+from zignal_amd.measure.mlstaps import TAPS
+
+
+def timed(fn, reps=5):
+    fn(); sync(0)
+    t = Timer(0); t.start()
+    for _ in range(reps):
+        fn()
+    t.stop()
+    return t.elapsed_ms() / reps
+
+
+B, A = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=96000).get_coefficients()
+f = IirFilter(A, B, device=0)
+for n, C, rs, cs, name in ((17 * (2**20 - 1), 1, 1, 1, "one channel, 17 periods of N=20"),
+                           (2 * (2**20 - 1), 512, 512, 1, "(2L, 512) frames x channels"),
+                           (17 * (2**20 - 1), 64, 64, 1, "(17L, 64) frames x channels"),
+                           (2 * (2**20 - 1), 512, 1, 2 * (2**20 - 1), "(512, 2L) stacked captures")):
+    d = DeviceBuffer(n * C * 8); d.fill(0)
+    y = DeviceBuffer(n * C * 8)
+    f.reserve(n, C)
+    ors, ocs = (C, 1) if cs == 1 else (1, n)
+    ms = timed(lambda: f.filter_device(d.ptr, _lib.ZMLS_F64, n, C, rs, cs, y.ptr, ors, ocs))
+    print("iir      %-34s %8.3f ms  %7.0f GB/s (read + write once = %.2f GB)" % (name, ms, 2 * n * C * 8 / ms / 1e6, 2 * n * C * 8 / 1e9), flush=True)
+    d.free(); y.free()
+
+for N, C in ((20, 1), (20, 64), (16, 512)):
+    L = 2**N - 1
+    sp = Spectrum(L, C, device=0)
+    h = DeviceBuffer(L * C * 8); h.fill(0)
+    m = DeviceBuffer(sp.n_bins * C * 8)
+    ms = timed(lambda: sp.magnitude_db_device(h.ptr, C, 1, None, False, m.ptr))
+    print("spectrum N=%d x %d channels             %8.3f ms  %7.0f GB/s (response in + spectrum out = %.3f GB)" % (N, C, ms, 1.5 * L * C * 8 / ms / 1e6, 1.5 * L * C * 8 / 1e9), flush=True)
+    sp.close(); h.free(); m.free()
+
+N, C, R = 20, 512, 17
+p = Plan(N, TAPS[N][0], device=0)
+L = p.L
+p.reserve(C, staging=True)
+x = DeviceBuffer(R * L * C * 8); x.fill(0)
+h = DeviceBuffer(L * C * 8)
+for name, args in (("frame-major in/out (fused gather)", (C, 1, C, 1)), ("stacked captures in, frame-major out", (1, R * L, C, 1)),
+                   ("stacked captures in and out", (1, R * L, 1, L)), ("frame-major in, stacked out", (C, 1, 1, L))):
+    rs, cs, ors, ocs = args
+    ms = timed(lambda: p.impulse_device(x.ptr, _lib.ZMLS_F64, R * L, C, rs, cs, h.ptr, ors, ocs), 3)
+    print("impulse  %-38s %8.3f ms  %7.0f GB/s algorithmic" % (name, ms, R * L * C * 8 / ms / 1e6), flush=True)

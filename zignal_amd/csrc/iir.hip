@@ -87,11 +87,28 @@ __global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict
     const int64_t chunk = blockIdx.x / n_cgrp;
     const int64_t t0 = chunk * TT, c0 = (int64_t)(blockIdx.x % n_cgrp) * CC;
 
-    for (int e = tid; e < TT * CC; e += 256) {
-        const int tt = e / CC, cc = e % CC;
-        const int64_t t = t0 + tt, c = c0 + cc;
-        const double v = (t < n_rows && c < n_ch) ? iir_load(x, t * rs + c * cs, in_dtype) : 0.0;
-        tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)] = v;
+    constexpr int PER = TT * CC / 256;             // elements per thread in the coalesced load / store sweeps (32)
+    if (in_dtype == ZMLS_F64 && t0 + TT <= n_rows && c0 + CC <= n_ch) {
+        // interior tile of float64 data: all loads of a thread issued back to back (the kernel is bound by memory
+        // latency otherwise: two workgroups per CU and one 8-byte load in flight per lane do not fill the HBM pipe)
+        double r[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * 256, tt = e / CC, cc = e % CC;
+            r[i] = ((const double *)x)[(t0 + tt) * rs + (c0 + cc) * cs];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * 256, tt = e / CC, cc = e % CC;
+            tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)] = r[i];
+        }
+    } else {
+        for (int e = tid; e < TT * CC; e += 256) {
+            const int tt = e / CC, cc = e % CC;
+            const int64_t t = t0 + tt, c = c0 + cc;
+            const double v = (t < n_rows && c < n_ch) ? iir_load(x, t * rs + c * cs, in_dtype) : 0.0;
+            tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)] = v;
+        }
     }
     __syncthreads();
 
@@ -167,16 +184,24 @@ __global__ void __launch_bounds__(64) iir_combine_kernel(const IirDev *__restric
     double s[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) s[k] = 0.0;        // lfilter starts at rest
-    for (int64_t q = 0; q < n_chunks; ++q) {
-        double e[S];
+    // the end states do not depend on the walk: fetch a batch of them ahead of the dependent chain
+    constexpr int AHEAD = 8;
+    for (int64_t q0 = 0; q0 < n_chunks; q0 += AHEAD) {
+        double e[AHEAD][S];
 #pragma unroll
-        for (int k = 0; k < S; ++k) {
-            sin[(q * n_ch + c) * S + k] = s[k];
-            e[k] = zc[(q * n_ch + c) * S + k];
+        for (int i = 0; i < AHEAD; ++i)
+#pragma unroll
+            for (int k = 0; k < S; ++k) e[i][k] = (q0 + i < n_chunks) ? zc[((q0 + i) * n_ch + c) * S + k] : 0.0;
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) {
+            if (q0 + i < n_chunks) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) sin[((q0 + i) * n_ch + c) * S + k] = s[k];
+                matvec_acc<S>(f->P[level], s, e[i]);          // e = A^chunk s + end_q
+#pragma unroll
+                for (int k = 0; k < S; ++k) s[k] = e[i][k];
+            }
         }
-        matvec_acc<S>(f->P[level], s, e);          // e = A^chunk s + end_q
-#pragma unroll
-        for (int k = 0; k < S; ++k) s[k] = e[k];
     }
 }
 
