@@ -137,13 +137,18 @@ def test_device_entry_point_chunks_channels_with_small_workspace():
     with pytest.raises(_lib.ZmlsError) as ei:
         p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)
     assert ei.value.code == _lib.E_WORKSPACE
-    p.reserve(8)                                  # room for one slab of the wider (big) tile = 4 small slabs
+    p.reserve(8)                                  # room for one slab of the small tile
     last = (1 << N) - 1                           # rows are padded: one extra row per 2^10 (and per 2^20) rows
-    assert p.info()["workspace_bytes"] == (last + (last >> 10) + (last >> 20) + 1) * 256
-    p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)     # 9 slabs -> 3 chunks
+    assert p.info()["workspace_bytes"] == (last + (last >> 10) + (last >> 20) + 1) * 64
+    p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)     # 9 slabs -> 9 chunks
     got = dh.download((L, C), np.float64)
     assert rel_err(got, want) <= 1e-14
-    p.force_tile(1)                               # big tile: 32 channels per slab -> 3 chunks of one slab
+    p.force_tile(1)                               # big tile: 32 channels per slab
+    with pytest.raises(_lib.ZmlsError) as ei:     # a small slab of workspace holds no big slab
+        p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)
+    assert ei.value.code == _lib.E_WORKSPACE
+    p.reserve(8)                                  # forced tile: room for one of its slabs -> 3 chunks of one slab
+    assert p.info()["workspace_bytes"] == (last + (last >> 10) + (last >> 20) + 1) * 256
     dh.fill(0)
     p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, C, C, 1, dh.ptr, C, 1)
     assert rel_err(dh.download((L, C), np.float64), want) <= 1e-14
@@ -328,4 +333,29 @@ def test_layout_adapters_on_the_device_entry_point(N, C, R, dtype, stage):
     d_h.fill(0xFF)
     p.impulse_device(d_i.ptr, _lib.ZMLS_I16, R * L, C, C, 1, d_h.ptr, C, 1)
     assert rel_err(d_h.download((L, C), npdt), want_i) <= tol
+    p.close()
+
+
+def test_order_26_single_capture_needs_only_a_small_slab_of_workspace():
+    """Orders beyond the BASELINE range (the reference's tap table goes to 32; this library to 30): a three-pass plan
+    of 2^26 points, two channels, checked against the known synthetic system; the workspace is one small-tile slab."""
+    from zignal_amd.device import Plan
+    N, C, R = 26, 2, 2
+    p = Plan(N, TAPS[N][0], device=0)
+    L = p.L
+    assert p.info()["passes"] == 3
+    d_x = DeviceBuffer(R * L * C * 8)
+    d_h = DeviceBuffer(L * C * 8)
+    p.reserve(C)
+    assert p.info()["workspace_bytes"] <= (1 << N) * 65
+    p.synth_device(d_x.ptr, _lib.ZMLS_F64, R, C, C, 1, seed=3, sigma=0.0)
+    p.impulse_device(d_x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, d_h.ptr, C, 1)
+    h = d_h.download((L, C), np.float64)
+    for c in range(C):
+        g, d = p.synth_system(c, seed=3)
+        want = np.zeros(L)
+        want[(d + np.arange(16)) % L] = g
+        want = want * (1.0 + 1.0 / L) - g.sum() / L
+        assert np.max(np.abs(h[:, c] - want)) <= 1e-12
+    assert np.array_equal(p.bits_packed(), c_oracle.bits_packed(N, TAPS[N][0]))
     p.close()

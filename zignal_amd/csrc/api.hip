@@ -176,10 +176,14 @@ int zmls_plan_reserve(zmls_plan *p, int64_t n_ch)
     if (p->npass == 1) return ZMLS_OK;   // single-pass plans keep everything in LDS
     int rc = use_device(p->device);
     if (rc) return rc;
-    // the wider slab of the two tile configurations bounds what either needs
+    // the widest slab among the tile configurations a call with n_ch channels can end up on: the small tile always, a
+    // wide one only when the batch fills at least one of its slabs or it is forced (a 256-byte slab of a 2^30-point
+    // transform alone is 275 GB: single-channel plans of the largest orders must not be charged for it)
     size_t need = 0;
     for (int c = 0; c < CFG_COUNT; ++c) {
         const int cs = chans_per_slab(p, c);
+        if (c != CFG_SMALL && n_ch < cs && p->force_cfg != c) continue;
+        if (c == CFG_BIG && p->force_cfg != CFG_BIG) continue;         // the big tile is only ever used when forced
         const size_t want = (size_t)((n_ch + cs - 1) / cs) * slab_bytes(p, c);
         if (want > need) need = want;
     }
