@@ -66,7 +66,8 @@ int zmls_plan_reserve(zmls_plan *p, int64_t n_ch);
  * Allocates; call outside timed/captured regions. */
 int zmls_plan_reserve_staging(zmls_plan *p, int64_t n_ch);
 /* info[0]=N info[1]=L info[2]=dtype info[3]=device info[4]=number of FWHT passes
- * info[5..7]=bits per pass info[8]=workspace bytes info[9]/info[10]=channels per slab of the small/big tile */
+ * info[5..7]=bits per pass info[8]=workspace bytes info[9]/info[10]/info[11]=channels per slab of the small/big/mid tile
+ * info[12]=bytes of each layout staging array */
 int zmls_plan_info(const zmls_plan *p, int64_t info[16]);
 /* Tile configuration used by the impulse entry points: -1 = chosen per call (default), 0 = small tile
  * (64 KiB, 64-byte row segments, any layout), 1 = big tile (256 KiB, 256-byte row segments), 2 = mid tile

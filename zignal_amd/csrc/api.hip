@@ -231,6 +231,7 @@ int zmls_plan_info(const zmls_plan *p, int64_t info[16])
     info[0] = p->N; info[1] = p->L; info[2] = p->dtype; info[3] = p->device; info[4] = p->npass;
     info[5] = p->bits[0]; info[6] = p->bits[1]; info[7] = p->bits[2];
     info[8] = (int64_t)p->work_bytes; info[9] = chans_per_slab(p, CFG_SMALL); info[10] = chans_per_slab(p, CFG_BIG);
+    info[11] = chans_per_slab(p, CFG_MID); info[12] = (int64_t)p->stage_bytes;
     return ZMLS_OK;
 }
 

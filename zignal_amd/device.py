@@ -82,7 +82,7 @@ class Plan:
         v = list(buf)
         return {"N": v[0], "L": v[1], "dtype": v[2], "device": v[3], "passes": v[4],
                 "pass_bits": [b for b in v[5:8] if b], "workspace_bytes": v[8], "channels_per_slab": v[9],
-                "channels_per_slab_big": v[10]}
+                "channels_per_slab_big": v[10], "channels_per_slab_mid": v[11], "staging_bytes": v[12]}
 
     def force_tile(self, cfg):
         """-1 auto, 0 small tile, 1 big tile (tests / tuning)"""
