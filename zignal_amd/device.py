@@ -211,6 +211,8 @@ class IirFilter:
 
     def filter_host(self, x):
         """x: (n,) or (n, C) ndarray -> float64 array of the same shape, filtered along axis 0."""
+        if np.size(x) == 0:
+            return np.zeros(np.shape(x), dtype=np.float64)      # lfilter of nothing is nothing
         x2, code, n_rows, n_ch, rs, cs = Plan._as_capture(np.asarray(x))
         y = np.empty((n_rows, n_ch), dtype=np.float64)
         L.check(L.lib().zmls_iir_host(self._h, x2.ctypes.data, code, n_rows, n_ch, rs, cs, y.ctypes.data))
