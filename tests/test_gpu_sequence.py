@@ -96,3 +96,24 @@ def test_non_maximal_taps_are_rejected_loudly():
     with pytest.raises(_lib.ZmlsError) as ei:
         plan(8, (8, 4))          # x^8 + x^4 + 1 is not primitive
     assert ei.value.code == _lib.E_UNSUPPORTED and "maximum-length" in str(ei.value)
+
+
+def test_every_tap_set_of_the_reference_table():
+    """The bit-exactness contract is 'against the reference taps': all tap sets of zignal's table up to
+    N = 22 give, bit for bit, the C oracle's period (which the goldens pin to the reference); for N = 23..26 every
+    set (27..30: the first and last) must build a plan (= the kernel's walk visits every state: maximum length) and agree on the first 64 Ki bits."""
+    from zignal_amd.device import Plan
+    n_sets = 0
+    for N in sorted(TAPS):
+        if N > 30:
+            continue                                  # tables are uint32 with a sentinel: orders 31, 32 are not built
+        for taps in (TAPS[N] if N <= 26 else (TAPS[N][0], TAPS[N][-1])):
+            p = Plan(N, taps, device=0)
+            if N <= 22:
+                assert np.array_equal(p.bits_packed(), c_oracle.bits_packed(N, taps)), "N=%d taps=%s" % (N, taps)
+            else:
+                nb = 1 << 16
+                assert np.array_equal(p.bits_packed(nb), c_oracle.bits_packed(N, taps, nb)), "N=%d taps=%s" % (N, taps)
+            p.close()
+            n_sets += 1
+    assert n_sets == sum(len(TAPS[N]) for N in TAPS if N <= 26) + 8
