@@ -23,6 +23,12 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     else:
         d_x, probe_ms = DeviceBuffer(R * L * C * 8), 0.0
     t_alloc = time.perf_counter() - t0
+    pre = np.zeros(2)
+    if mode == "chosen":          # same buffer, still holding the probe's zeros, after the rejected candidates were freed
+        for rep in range(3):
+            t = np.array(plan.impulse_device_timed(d_x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, d_h.ptr, C, 1))
+            if rep:
+                pre += t / 2
     plan.synth_device(d_x.ptr, _lib.ZMLS_F64, R, C, C, 1)
     sync(0)
     ms = np.zeros(2)
@@ -31,5 +37,5 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
         if rep:
             ms += t
     ms /= 3
-    print("trial %d %s ptr %#x alloc %.3f s probe %.3f ms pass_ms %s" % (trial, mode, d_x.ptr, t_alloc, probe_ms, np.round(ms, 3)), flush=True)
+    print("trial %d %s ptr %#x alloc %.3f s probe %.3f ms zeros-after-cleanup %.3f pass_ms %s" % (trial, mode, d_x.ptr, t_alloc, probe_ms, pre[0], np.round(ms, 3)), flush=True)
     d_x.free()

@@ -566,42 +566,69 @@ int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch,
     ZHIP(hipEventCreate(&ev[0]));
     ZHIP(hipEventCreate(&ev[1]));
     void *best = nullptr, *rejected[2] = {nullptr, nullptr};
-    float best_ms = 0.f, second_ms = 0.f;
+    float best_ms = 0.f;
     auto reject = [&](void *q) {
         if (rejected[0]) (void)hipFree(rejected[0]);      // at most two rejected candidates are held at a time
         rejected[0] = rejected[1];
         rejected[1] = q;
     };
-    for (int t = 0; t < tries; ++t) {
-        void *cand = nullptr;
-        hipError_t e = hipMalloc(&cand, bytes);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            if (!best) { rc = hip_fail(e, "hipMalloc(capture)"); }
-            break;                                        // memory is full of candidates: settle for the best so far
-        }
+    // gather-pass time on a candidate: the first run warms up, the faster of the next two counts
+    auto rate = [&](void *cand, float *ms_out) -> int {
         float ms = 0.f, pass_ms[4];
-        e = hipMemsetAsync(cand, 0, bytes, 0);
-        for (int rep = 0; rep < 3 && e == hipSuccess && !rc; ++rep) {     // first run warms up, the faster of the next two counts
+        for (int rep = 0; rep < 3; ++rep) {
             pass_ms[0] = 0.f;
-            rc = impulse_device_core(p, cand, in_dtype, periods, 1, periods, n_ch, n_ch, 1, nullptr, n_ch, 1, 0, ev, pass_ms, 1);
+            int r = impulse_device_core(p, cand, in_dtype, periods, 1, periods, n_ch, n_ch, 1, nullptr, n_ch, 1, 0, ev, pass_ms, 1);
+            if (r) return r;
             if (rep == 1 || (rep == 2 && pass_ms[0] < ms)) ms = pass_ms[0];
         }
-        if (e != hipSuccess && !rc) rc = hip_fail(e, "capture placement probe");
-        if (rc) { (void)hipFree(cand); break; }
-        if (!best || ms < best_ms) {
-            if (best) reject(best);
-            second_ms = best ? best_ms : 0.f;
-            best = cand; best_ms = ms;
-        } else {
-            if (second_ms == 0.f || ms < second_ms) second_ms = ms;
-            reject(cand);
+        *ms_out = ms;
+        return ZMLS_OK;
+    };
+    // A placement can lose its speed when the candidates it was compared with are given back (seen about once in
+    // twelve searches: 12.6 ms before, 13.6 ms after, for the life of the buffer). So the winner is rated again after
+    // the others are freed, and if it no longer holds its time the search is repeated with it held as a reject.
+    for (int round = 0; round < 3 && !rc; ++round) {
+        float second_ms = 0.f;
+        void *held = best;                                // the degraded winner of the round before, if any
+        best = nullptr; best_ms = 0.f;
+        for (int t = 0; t < tries; ++t) {
+            void *cand = nullptr;
+            hipError_t e = hipMalloc(&cand, bytes);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                if (!best && !held) rc = hip_fail(e, "hipMalloc(capture)");
+                break;                                    // memory is full of candidates: settle for the best so far
+            }
+            float ms = 0.f;
+            e = hipMemsetAsync(cand, 0, bytes, 0);
+            if (e != hipSuccess) rc = hip_fail(e, "capture placement probe");
+            if (!rc) rc = rate(cand, &ms);
+            if (rc) { (void)hipFree(cand); break; }
+            if (!best || ms < best_ms) {
+                if (best) reject(best);
+                second_ms = best ? best_ms : 0.f;
+                best = cand; best_ms = ms;
+            } else {
+                if (second_ms == 0.f || ms < second_ms) second_ms = ms;
+                reject(cand);
+            }
+            // two candidates within 2 % of each other at the top: that is the floor, stop looking
+            if (second_ms > 0.f && second_ms <= best_ms * 1.02f) break;
         }
-        // two candidates within 2 % of each other at the top: that is the floor, stop looking
-        if (second_ms > 0.f && second_ms <= best_ms * 1.02f) break;
+        for (int i = 0; i < 2; ++i) {
+            if (rejected[i]) (void)hipFree(rejected[i]);
+            rejected[i] = nullptr;
+        }
+        if (rc) break;
+        if (!best) { best = held; held = nullptr; break; }      // nothing new could be allocated: keep what there is
+        if (held) (void)hipFree(held);
+        float again = 0.f;
+        rc = rate(best, &again);
+        if (rc) break;
+        const bool holds = again <= best_ms * 1.03f;
+        best_ms = again;
+        if (holds) break;
     }
-    for (int i = 0; i < 2; ++i)
-        if (rejected[i]) (void)hipFree(rejected[i]);
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
     if (rc) { if (best) (void)hipFree(best); return rc; }
