@@ -67,11 +67,14 @@ int zmls_plan_reserve(zmls_plan *p, int64_t n_ch);
 int zmls_plan_reserve_staging(zmls_plan *p, int64_t n_ch);
 /* info[0]=N info[1]=L info[2]=dtype info[3]=device info[4]=number of FWHT passes
  * info[5..7]=bits per pass info[8]=workspace bytes info[9]/info[10]/info[11]=channels per slab of the small/big/mid tile
- * info[12]=bytes of each layout staging array */
+ * info[12]=bytes of each layout staging array
+ * info[13]=passes of the tall-tile schedule (2 for N = 21, 22: wide aligned batches then take 11-bit passes, two
+ * instead of info[4]'s three; 0 elsewhere) info[14..15]=its bits per pass */
 int zmls_plan_info(const zmls_plan *p, int64_t info[16]);
 /* Tile configuration used by the impulse entry points: -1 = chosen per call (default), 0 = small tile
  * (64 KiB, 64-byte row segments, any layout), 1 = big tile (256 KiB, 256-byte row segments), 2 = mid tile
- * (128 KiB, 128-byte row segments); 1 and 2 need contiguous, 16-byte aligned channels. Tuning bits: +256
+ * (128 KiB, 128-byte row segments), 3 = tall tile (256 KiB, 2^11 rows of 128 bytes; orders 21 and 22 only);
+ * 1, 2 and 3 need contiguous, 16-byte aligned channels. Tuning bits: +256
  * switches the XCD-aware block mapping off, +1024 lays the workspace out row-major. */
 int zmls_plan_force_tile(zmls_plan *p, int cfg);
 

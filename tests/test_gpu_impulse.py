@@ -234,11 +234,13 @@ def test_mls_and_mls_simple_classes_against_reference_goldens():
 
 @pytest.mark.parametrize("N,C,dtype", [(11, 32, "f64"), (12, 64, "f64"), (13, 96, "f64"), (15, 40, "f64"), (16, 64, "f64"),
                                         (17, 32, "f64"), (18, 64, "f64"), (19, 32, "f64"), (20, 32, "f64"), (21, 32, "f64"),
-                                        (14, 64, "f32"), (18, 128, "f32"), (20, 64, "f32")])
+                                        (22, 16, "f64"), (14, 64, "f32"), (18, 128, "f32"), (20, 64, "f32"), (21, 64, "f32"),
+                                        (22, 32, "f32")])
 def test_big_tile_against_small_tile_and_oracle(N, C, dtype):
-    """Wide, contiguous channel blocks go through the 256 KiB register-resident tile (256-byte row
-    segments); the result must equal the small tile's to round-off and the oracle's within tolerance.
-    Covers 2-pass (N<=20) and 3-pass (N=21) plans and a ragged last slab (C=40, C=96)."""
+    """Wide, contiguous channel blocks go through the register-resident tiles (128- and 256-byte row
+    segments); the results must equal the small tile's to round-off and the oracle's within tolerance.
+    Covers 2-pass (N<=20) and 3-pass (N=21, 22) plans, a ragged last slab (C=40, C=96), and the tall tile's
+    two-pass schedule (11+10, 11+11 bits) that orders 21 and 22 take by default."""
     taps = TAPS[N][0]
     L = (1 << N) - 1
     R = 3 if N <= 18 else 2
@@ -255,7 +257,18 @@ def test_big_tile_against_small_tile_and_oracle(N, C, dtype):
     h_small = p.impulse_host(x)
     p.force_tile(-1)
     h_auto = p.impulse_host(x)
-    assert np.array_equal(h_auto, h_mid)                      # auto picks the mid tile for such input
+    if N in (21, 22):
+        assert p.info()["tall_passes"] == 2
+        p.force_tile(3)
+        h_tall = p.impulse_host(x)
+        p.force_tile(-1)
+        assert np.array_equal(h_auto, h_tall)                 # auto picks the tall tile where it saves a pass
+        assert rel_err(h_tall, h_mid.astype(np.float64)) <= (1e-14 if dtype == "f64" else 1e-5)
+    else:
+        assert p.info()["tall_passes"] == 0
+        with pytest.raises(Exception):
+            p.force_tile(3)
+        assert np.array_equal(h_auto, h_mid)                  # auto picks the mid tile for such input
     tol = TOL64 if dtype == "f64" else TOL32
     assert rel_err(h_big, h_small.astype(np.float64)) <= (1e-14 if dtype == "f64" else 1e-5)
     ref = c_oracle.sequence(N, taps)

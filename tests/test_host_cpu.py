@@ -56,9 +56,15 @@ def test_pass_split(lib):
 @pytest.mark.parametrize("K", range(1, 11))
 @pytest.mark.parametrize("cfg", [0, 1, 2])
 def test_tile_geometry_is_a_tiling(lib, cfg, K, first):
-    if cfg == 2 and K == 10 and False:
-        pytest.skip("")
     assert lib.zmls_host_geometry_selfcheck(K, cfg, first) == 0, _lib.last_error()
+
+
+@pytest.mark.parametrize("first", [0, 1])
+@pytest.mark.parametrize("K", [10, 11])
+def test_tall_tile_geometry_is_a_tiling(lib, K, first):
+    assert lib.zmls_host_geometry_selfcheck(K, 3, first) == 0, _lib.last_error()
+    assert lib.zmls_host_geometry_selfcheck(12, 3, first) != 0
+    assert lib.zmls_host_geometry_selfcheck(11, 2, first) != 0      # 11-bit passes are the tall tile's alone
 
 
 def _window(N, taps, steps):

@@ -106,12 +106,18 @@ int build_plan(zmls_plan *p)
         return ZMLS_E_UNSUPPORTED;
     }
     p->npass = pass_split(p->N, p->bits);
+    // the tall tile earns its single workgroup per CU only where its 11-bit passes save a whole pass over HBM: N = 21, 22
+    p->tall_npass = pass_split(p->N, p->tall_bits, kTallPassBits);
+    if (!(p->npass == 3 && p->tall_npass == 2)) p->tall_npass = 0;
     if (p->npass > 1) {
-        int b = 0;
-        for (int i = 0; i + 1 < p->npass; ++i) b += p->bits[i];
         for (int c = 0; c < CFG_COUNT; ++c) {
+            const int np = (c == CFG_TALL) ? p->tall_npass : p->npass;
+            const int *bits = (c == CFG_TALL) ? p->tall_bits : p->bits;
+            if (!np) continue;
+            int b = 0;
+            for (int i = 0; i + 1 < np; ++i) b += bits[i];
             ZHIP(hipMalloc((void **)&p->d_scatter_perm[c], n * 4));
-            rc = launch_scatter_perm(p->N, p->bits[p->npass - 1], kCfg[c], b, p->d_scatter_nat, p->d_scatter_perm[c], 0);
+            rc = launch_scatter_perm(p->N, bits[np - 1], kCfg[c], b, p->d_scatter_nat, p->d_scatter_perm[c], 0);
             if (rc) return rc;
         }
     }
@@ -184,6 +190,7 @@ int zmls_plan_reserve(zmls_plan *p, int64_t n_ch)
         const int cs = chans_per_slab(p, c);
         if (c != CFG_SMALL && n_ch < cs && p->force_cfg != c) continue;
         if (c == CFG_BIG && p->force_cfg != CFG_BIG) continue;         // the big tile is only ever used when forced
+        if (c == CFG_TALL && !p->tall_npass) continue;
         const size_t want = (size_t)((n_ch + cs - 1) / cs) * slab_bytes(p, c);
         if (want > need) need = want;
     }
@@ -217,7 +224,8 @@ int zmls_plan_reserve_staging(zmls_plan *p, int64_t n_ch)
 
 int zmls_plan_force_tile(zmls_plan *p, int cfg)
 {
-    if (!p || cfg < -1 || (cfg >= 0 && (cfg & 0xFF) >= CFG_COUNT)) { set_error("tile configuration must be -1 (auto), 0 (small), 1 (big) or 2 (mid)"); return ZMLS_E_ARG; }
+    if (!p || cfg < -1 || (cfg >= 0 && (cfg & 0xFF) >= CFG_COUNT)) { set_error("tile configuration must be -1 (auto), 0 (small), 1 (big), 2 (mid) or 3 (tall)"); return ZMLS_E_ARG; }
+    if (cfg >= 0 && (cfg & 0xFF) == CFG_TALL && !p->tall_npass) { set_error("the tall tile exists for orders 21 and 22 only"); return ZMLS_E_UNSUPPORTED; }
     p->swizzle = (cfg >= 0 && (cfg & 0x100)) ? 0 : 1;     // +256: switch the XCD-aware block mapping off (tuning)
         p->work_layout = (cfg >= 0 && (cfg & 0x400)) ? 1 : 0; // +1024: row-major workspace (tuning)
     p->force_cfg = cfg < 0 ? -1 : (cfg & 0xFF);
@@ -232,6 +240,7 @@ int zmls_plan_info(const zmls_plan *p, int64_t info[16])
     info[5] = p->bits[0]; info[6] = p->bits[1]; info[7] = p->bits[2];
     info[8] = (int64_t)p->work_bytes; info[9] = chans_per_slab(p, CFG_SMALL); info[10] = chans_per_slab(p, CFG_BIG);
     info[11] = chans_per_slab(p, CFG_MID); info[12] = (int64_t)p->stage_bytes;
+    info[13] = p->tall_npass; info[14] = p->tall_bits[0]; info[15] = p->tall_bits[1];
     return ZMLS_OK;
 }
 
@@ -302,12 +311,14 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
     // register-resident workgroups per CU); everything else, and every single-pass order, through the small one
     // (measured on the N=20, 512-channel, 16-period batch: small 19.3 ms, big 15.9 ms, mid 14.9 ms per step)
     int cfg = CFG_SMALL;
-    if (vec_in && vec_out && n_ch >= chans_per_slab(p, CFG_MID) && p->force_cfg != CFG_SMALL) cfg = CFG_MID;
+    if (vec_in && vec_out && n_ch >= chans_per_slab(p, CFG_MID) && p->force_cfg != CFG_SMALL) cfg = p->tall_npass ? CFG_TALL : CFG_MID;
     if (p->force_cfg > CFG_SMALL) {
         if (!(vec_in && vec_out)) { set_error("the wide tiles need vector-aligned contiguous channels"); return ZMLS_E_ARG; }
         cfg = p->force_cfg;
     }
     const TileCfg tc = kCfg[cfg];
+    const int npass = (cfg == CFG_TALL) ? p->tall_npass : p->npass;
+    const int *pass_bits = (cfg == CFG_TALL) ? p->tall_bits : p->bits;
     const int CS = chans_per_slab(p, cfg);
     const int64_t n_slabs = (n_ch + CS - 1) / CS;
 
@@ -355,14 +366,14 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
         a.work_slab_stride = p->work_layout ? U : work_rows_total(p->N) * U;
         a.work_row_stride = p->work_layout ? (uint64_t)ns * U : U;
         int b = 0;
-        for (int i = 0; i < (gather_pass_only ? 1 : p->npass); ++i) {
-            const int K = p->bits[i];
+        for (int i = 0; i < (gather_pass_only ? 1 : npass); ++i) {
+            const int K = pass_bits[i];
             const int LT = log2_tiles(K, tc);
             a.b = b;
             a.n_macro = (uint32_t)(1u << (p->N - K - LT));
             const uint64_t total = (uint64_t)a.n_macro * ns;
             const int inm = (i == 0) ? (vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM) : IN_WORK;
-            const int outm = (i == p->npass - 1) ? (vec_out ? OUT_SCATTER_VEC : OUT_SCATTER_ELEM) : OUT_WORK;
+            const int outm = (i == npass - 1) ? (vec_out ? OUT_SCATTER_VEC : OUT_SCATTER_ELEM) : OUT_WORK;
             if (cfg == CFG_BIG) a.swz_group = 0;
             else if (p->swizzle == 0) a.swz_group = 0;
             else if (i == 0 || p->work_layout) a.swz_group = (a.n_macro % 8 == 0) ? ns : 0;
@@ -374,7 +385,7 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
             b += K;
         }
         if (ev)
-            for (int i = 0; i < (gather_pass_only ? 1 : p->npass); ++i) {
+            for (int i = 0; i < (gather_pass_only ? 1 : npass); ++i) {
                 float ms = 0.f;
                 ZHIP(hipEventSynchronize(ev[2 * i + 1]));
                 ZHIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));

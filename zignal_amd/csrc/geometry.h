@@ -17,6 +17,7 @@
 //   small  LOGV=12 RB=4 LU=2 :  64 KiB tile, 256 threads, 2 workgroups/CU,  64-byte row segments
 //   mid    LOGV=13 RB=5 LU=3 : 128 KiB tile, 256 threads, 2 workgroups/CU, 128-byte row segments
 //   big    LOGV=14 RB=5 LU=4 : 256 KiB tile, 512 threads, 1 workgroup/CU,  256-byte row segments
+//   tall   LOGV=14 RB=5 LU=3 : 256 KiB tile, 512 threads, 1 workgroup/CU,  128-byte row segments, 2^11 rows
 // The wider ones exist because random row gathers from HBM run at 3.2 / 5.2 / 5.7 TB/s for 64 / 128 /
 // 256-byte segments on MI355X (tools/gather_probe.hip); their tiles live in the register file
 // (512 KiB per CU) and go through LDS in two halves.
@@ -32,6 +33,7 @@
 namespace zmls {
 
 constexpr int kMaxPassBits = 10;
+constexpr int kTallPassBits = 11;   // the tall tile's passes (zmls_internal.h)
 constexpr int kVecBytes = 16;
 
 struct TileCfg {
@@ -136,10 +138,10 @@ ZHD constexpr uint64_t row_of_logical(uint64_t macro, uint32_t l, int b, int K, 
 ZHD constexpr uint64_t work_row(uint64_t d) { return d + (d >> 10) + (d >> 20); }
 ZHD constexpr uint64_t work_rows_total(int N) { return work_row((1ull << N) - 1ull) + 1ull; }
 
-// How N transform bits are split into passes of at most kMaxPassBits bits (low bits first).
-ZHD constexpr int pass_split(int N, int bits[4])
+// How N transform bits are split into passes of at most max_bits bits (low bits first).
+ZHD constexpr int pass_split(int N, int bits[4], int max_bits = kMaxPassBits)
 {
-    const int np = (N + kMaxPassBits - 1) / kMaxPassBits;
+    const int np = (N + max_bits - 1) / max_bits;
     const int base = N / np, rem = N % np;
     for (int i = 0; i < np; ++i) bits[i] = base + (i < rem ? 1 : 0);
     for (int i = np; i < 4; ++i) bits[i] = 0;

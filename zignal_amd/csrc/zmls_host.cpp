@@ -110,7 +110,7 @@ int zmls_host_geometry_selfcheck(int K, int cfg_id, int first_pass)
 {
     if (cfg_id < 0 || cfg_id >= CFG_COUNT) { set_error("bad tile configuration"); return ZMLS_E_ARG; }
     const TileCfg C = kCfg[cfg_id];
-    if (K < 1 || K > kMaxPassBits || log2_tiles(K, C) < 0) { set_error("bad geometry arguments"); return ZMLS_E_ARG; }
+    if (K < 1 || K > (cfg_id == CFG_TALL ? kTallPassBits : kMaxPassBits) || log2_tiles(K, C) < 0) { set_error("bad geometry arguments"); return ZMLS_E_ARG; }
     const int NB = cfg_logical_bits(C);
     const uint32_t n_log = 1u << NB;
     const int LUP = C.lu - cfg_log2_phases(C);

@@ -13,8 +13,9 @@ constexpr int kSynthTaps = 16;
 
 // tile configurations (geometry.h). CFG_SMALL is the general one (any channel count, any strides,
 // single-pass orders); CFG_BIG is the streaming one for wide, vector-aligned channel blocks.
-enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_MID = 2, CFG_COUNT = 3 };
-constexpr TileCfg kCfg[CFG_COUNT] = {{12, 4, 2, 12}, {14, 5, 4, 13}, {13, 5, 3, 12}};
+// CFG_TALL holds 2^11 rows of 128 bytes: orders 21 and 22 then take two passes (11+10, 11+11) instead of three.
+enum { CFG_SMALL = 0, CFG_BIG = 1, CFG_MID = 2, CFG_TALL = 3, CFG_COUNT = 4 };
+constexpr TileCfg kCfg[CFG_COUNT] = {{12, 4, 2, 12}, {14, 5, 4, 13}, {13, 5, 3, 12}, {14, 5, 3, 13}};
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
@@ -129,6 +130,8 @@ struct zmls_plan {
     int device;
     int npass;
     int bits[4];
+    int tall_npass;               // pass split of the tall tile (11 bits per pass), 0 when it saves no pass
+    int tall_bits[4];
     uint32_t s0;                  // Fibonacci state at n = 0 (first N sequence bits)
     uint32_t *d_bits;             // packed sequence bits, n_words uint32
     uint64_t n_words;

@@ -82,10 +82,11 @@ class Plan:
         v = list(buf)
         return {"N": v[0], "L": v[1], "dtype": v[2], "device": v[3], "passes": v[4],
                 "pass_bits": [b for b in v[5:8] if b], "workspace_bytes": v[8], "channels_per_slab": v[9],
-                "channels_per_slab_big": v[10], "channels_per_slab_mid": v[11], "staging_bytes": v[12]}
+                "channels_per_slab_big": v[10], "channels_per_slab_mid": v[11], "staging_bytes": v[12],
+                "tall_passes": v[13], "tall_pass_bits": [b for b in v[14:16] if b]}
 
     def force_tile(self, cfg):
-        """-1 auto, 0 small tile, 1 big tile (tests / tuning)"""
+        """-1 auto, 0 small, 1 big, 2 mid, 3 tall tile (tests / tuning)"""
         L.check(L.lib().zmls_plan_force_tile(self._h, int(cfg)))
 
     def reserve(self, n_ch, staging=False):
