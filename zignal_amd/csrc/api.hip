@@ -69,8 +69,10 @@ void free_plan_buffers(zmls_plan *p)
         if (p->d_scatter_perm[c]) (void)hipFree(p->d_scatter_perm[c]);
     if (p->d_jt) (void)hipFree(p->d_jt);
     if (p->d_work) (void)hipFree(p->d_work);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (p->d_stage[i]) (void)hipFree(p->d_stage[i]);
+        if (p->d_host_call[i]) (void)hipFree(p->d_host_call[i]);
+    }
 }
 
 int build_plan(zmls_plan *p)
@@ -502,6 +504,25 @@ int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64
     return rc;
 }
 
+// Device buffers of the host entry point: kept with the plan (grow-only) while they are small, so that the
+// reference's own call pattern - one short capture per call - does not pay two hipMalloc/hipFree pairs (each a
+// device synchronisation) per call; large ones are allocated and freed per call.
+static int host_call_buffer(zmls_plan *p, int which, size_t need, void **out, bool *per_call)
+{
+    constexpr size_t kKeep = (size_t)256 << 20;
+    *per_call = need > kKeep;
+    if (*per_call) { ZHIP(hipMalloc(out, need)); return ZMLS_OK; }
+    if (p->host_call_bytes[which] < need) {
+        if (p->d_host_call[which]) { ZHIP(hipFree(p->d_host_call[which])); p->d_host_call[which] = nullptr; p->host_call_bytes[which] = 0; }
+        size_t cap = (size_t)1 << 20;
+        while (cap < need) cap <<= 1;
+        ZHIP(hipMalloc(&p->d_host_call[which], cap));
+        p->host_call_bytes[which] = cap;
+    }
+    *out = p->d_host_call[which];
+    return ZMLS_OK;
+}
+
 int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
                       int64_t ch_stride, void *h, int64_t out_row_stride, int64_t out_ch_stride)
 {
@@ -509,9 +530,10 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
     const size_t is = dtype_size(in_dtype), ts = dtype_size(p->dtype);
     if (!is) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
     if (n_ch < 1 || n_rows < 1 || row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
-    if (n_rows <= p->L) { set_error("The first sequence will be thrown away: need more than L=%lld frames", (long long)p->L); return ZMLS_E_ARG; }
-    if (n_rows % p->L) { set_error("frame count %lld is not a multiple of L=%lld", (long long)n_rows, (long long)p->L); return ZMLS_E_ARG; }
-    int rc = use_device(p->device);
+    int64_t periods = 0;
+    int rc = capture_periods(p, n_rows, &periods);
+    if (rc) return rc;
+    rc = use_device(p->device);
     if (rc) return rc;
     rc = zmls_plan_reserve(p, n_ch);
     if (rc) return rc;
@@ -524,23 +546,35 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
             if (rc) return rc;
         }
     }
-    const size_t in_span = (size_t)((n_rows - 1) * row_stride + (n_ch - 1) * ch_stride + 1) * is;
+    // The first period is thrown away (mls.py:284): it never crosses PCIe. The device copy starts at frame L.
+    const int64_t rows = periods * p->L;
+    const bool stacked = row_stride == 1 && n_ch > 1 && ch_stride >= n_rows;       // (channels, frames): one run of frames per channel
+    const int64_t dev_cs = stacked ? rows : ch_stride;
+    const size_t in_span = stacked ? (size_t)rows * (size_t)n_ch * is
+                                   : (size_t)((rows - 1) * row_stride + (n_ch - 1) * ch_stride + 1) * is;
     const size_t out_span = (size_t)((p->L - 1) * out_row_stride + (n_ch - 1) * out_ch_stride + 1) * ts;
+    const bool out_dense = out_span == (size_t)p->L * (size_t)n_ch * ts;          // every byte of the span is ours
+    const char *x_from = (const char *)x + (size_t)p->L * (size_t)row_stride * is;
     void *d_x = nullptr, *d_h = nullptr;
-    hipError_t e = hipMalloc(&d_x, in_span);
-    if (e == hipSuccess) e = hipMalloc(&d_h, out_span);
-    if (e == hipSuccess) e = hipMemcpy(d_x, x, in_span, hipMemcpyHostToDevice);
-    // the output may be a strided view: keep the bytes between the elements we own
-    if (e == hipSuccess) e = hipMemcpy(d_h, h, out_span, hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = hip_fail(e, "impulse_host staging");
-    if (!rc) rc = zmls_impulse_device(p, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride, nullptr);
+    bool free_x = false, free_h = false;
+    rc = host_call_buffer(p, 0, in_span, &d_x, &free_x);
+    if (!rc) rc = host_call_buffer(p, 1, out_span, &d_h, &free_h);
     if (!rc) {
-        e = hipDeviceSynchronize();
-        if (e == hipSuccess) e = hipMemcpy(h, d_h, out_span, hipMemcpyDeviceToHost);
+        hipError_t e;
+        if (stacked) e = hipMemcpy2D(d_x, (size_t)rows * is, x_from, (size_t)ch_stride * is, (size_t)rows * is, (size_t)n_ch, hipMemcpyHostToDevice);
+        else e = hipMemcpy(d_x, x_from, in_span, hipMemcpyHostToDevice);
+        // a strided view of a larger array: keep the bytes between the elements we own
+        if (e == hipSuccess && !out_dense) e = hipMemcpy(d_h, h, out_span, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "impulse_host upload");
+    }
+    if (!rc) rc = impulse_device_core(p, d_x, in_dtype, periods, 0, periods, n_ch, row_stride, dev_cs, d_h, out_row_stride, out_ch_stride,
+                                      nullptr, nullptr, nullptr, 0);
+    if (!rc) {
+        hipError_t e = hipMemcpy(h, d_h, out_span, hipMemcpyDeviceToHost);      // null stream: ordered after the kernels
         if (e != hipSuccess) rc = hip_fail(e, "impulse_host download");
     }
-    if (d_x) (void)hipFree(d_x);
-    if (d_h) (void)hipFree(d_h);
+    if (free_x && d_x) (void)hipFree(d_x);
+    if (free_h && d_h) (void)hipFree(d_h);
     return rc;
 }
 

@@ -143,6 +143,8 @@ struct zmls_plan {
     size_t work_bytes;
     void *d_stage[2];             // frame-major staging (sums in, responses out) for captures in other layouts
     size_t stage_bytes;           // each
+    void *d_host_call[2];         // capture / response buffers of zmls_impulse_host, kept while small
+    size_t host_call_bytes[2];
     int force_cfg;                // -1: choose per call; else a tile configuration (tests, tuning)
     int swizzle;                  // XCD-aware block mapping on/off (tuning)
     int work_layout;              // 0: workspace slab-major, 1: row-major with slab-fastest block order in every pass
