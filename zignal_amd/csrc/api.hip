@@ -136,8 +136,10 @@ extern "C" {
 
 int zmls_device_count(int *n)
 {
+    if (!n) { set_error("null argument"); return ZMLS_E_ARG; }
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) (void)hipGetLastError();
     *n = (e == hipSuccess) ? c : 0;
     return ZMLS_OK;
 }
@@ -229,14 +231,14 @@ int zmls_plan_force_tile(zmls_plan *p, int cfg)
     if (!p || cfg < -1 || (cfg >= 0 && (cfg & 0xFF) >= CFG_COUNT)) { set_error("tile configuration must be -1 (auto), 0 (small), 1 (big), 2 (mid) or 3 (tall)"); return ZMLS_E_ARG; }
     if (cfg >= 0 && (cfg & 0xFF) == CFG_TALL && !p->tall_npass) { set_error("the tall tile exists for orders 21 and 22 only"); return ZMLS_E_UNSUPPORTED; }
     p->swizzle = (cfg >= 0 && (cfg & 0x100)) ? 0 : 1;     // +256: switch the XCD-aware block mapping off (tuning)
-        p->work_layout = (cfg >= 0 && (cfg & 0x400)) ? 1 : 0; // +1024: row-major workspace (tuning)
+    p->work_layout = (cfg >= 0 && (cfg & 0x400)) ? 1 : 0; // +1024: row-major workspace (tuning)
     p->force_cfg = cfg < 0 ? -1 : (cfg & 0xFF);
     return ZMLS_OK;
 }
 
 int zmls_plan_info(const zmls_plan *p, int64_t info[16])
 {
-    if (!p) { set_error("null plan"); return ZMLS_E_ARG; }
+    if (!p || !info) { set_error("null argument"); return ZMLS_E_ARG; }
     memset(info, 0, sizeof(int64_t) * 16);
     info[0] = p->N; info[1] = p->L; info[2] = p->dtype; info[3] = p->device; info[4] = p->npass;
     info[5] = p->bits[0]; info[6] = p->bits[1]; info[7] = p->bits[2];
