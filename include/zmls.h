@@ -226,6 +226,7 @@ int zmls_dev_free(int device, void *d_ptr);
 int zmls_dev_upload(int device, void *d_dst, const void *src, size_t bytes);
 int zmls_dev_download(int device, void *dst, const void *d_src, size_t bytes);
 int zmls_dev_memset(int device, void *d_ptr, int value, size_t bytes);
+int zmls_dev_copy(int device, void *d_dst, const void *d_src, size_t bytes, void *hip_stream);   /* device to device, asynchronous */
 int zmls_dev_sync(int device);
 int zmls_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
 int zmls_stream_create(int device, void **stream);

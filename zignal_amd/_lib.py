@@ -71,6 +71,7 @@ SIGNATURES = {
     "zmls_dev_upload": [c_int, c_vp, c_vp, c_sz],
     "zmls_dev_download": [c_int, c_vp, c_vp, c_sz],
     "zmls_dev_memset": [c_int, c_vp, c_int, c_sz],
+    "zmls_dev_copy": [c_int, c_vp, c_vp, c_sz, c_vp],
     "zmls_dev_sync": [c_int],
     "zmls_dev_mem_info": [c_int, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)],
     "zmls_stream_create": [c_int, _vpp],

@@ -773,6 +773,14 @@ int zmls_dev_memset(int device, void *d_ptr, int value, size_t bytes)
     ZHIP(hipMemset(d_ptr, value, bytes));
     return ZMLS_OK;
 }
+int zmls_dev_copy(int device, void *d_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (!d_dst || !d_src) { set_error("null argument"); return ZMLS_E_ARG; }
+    int rc = use_device(device);
+    if (rc) return rc;
+    ZHIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ZMLS_OK;
+}
 int zmls_dev_sync(int device)
 {
     int rc = use_device(device);
