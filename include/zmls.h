@@ -77,6 +77,14 @@ int zmls_plan_info(const zmls_plan *p, int64_t info[16]);
  * 1, 2 and 3 need contiguous, 16-byte aligned channels. Tuning bits: +256
  * switches the XCD-aware block mapping off, +1024 lays the workspace out row-major. */
 int zmls_plan_force_tile(zmls_plan *p, int cfg);
+/* Raw PCM captures: replaces Audio.convert_to_float (zignal/audio.py:565-589, samples / 2^(sourcebits-1)) on the
+ * way from sndcard.PA.play_rec / a wav file (zignal/sndcard.py:296-318, audio.py:1108-1123) to get_impulse.
+ * With k = sourcebits-1 set, the impulse entry points take the int16/int32 frames as they are (ZMLS_I16/ZMLS_I32,
+ * a quarter / half of the float64 bytes over PCIe and out of HBM) and return the responses of the converted
+ * capture: the division by 2^k is folded into the final 1/L scale, which is exact (a power of two commutes
+ * with every rounding on the path). k = 0 (default): samples are taken at face value, as numpy does when the
+ * reference is handed an integer array. State of the plan; 0 <= k <= 63. */
+int zmls_plan_set_input_scale_log2(zmls_plan *p, int k);
 
 /* ---- sequence: replaces generator_bit / generator_chunk / generator_samples /
  * get_full_sequence (mls.py:91-167). */

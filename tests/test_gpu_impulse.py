@@ -372,3 +372,46 @@ def test_order_26_single_capture_needs_only_a_small_slab_of_workspace():
         assert np.max(np.abs(h[:, c] - want)) <= 1e-12
     assert np.array_equal(p.bits_packed(), c_oracle.bits_packed(N, TAPS[N][0]))
     p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,np_dt", [(10, 1, np.int16), (14, 1, np.int16), (16, 1, np.int32), (17, 6, np.int16),
+                                        (18, 16, np.int32), (12, 3, np.int32)])
+def test_raw_pcm_captures_equal_convert_to_float_then_get_impulse(N, C, np_dt):
+    """int16/int32 frames straight from the sound card / a wav file. The fused path must give
+    what Audio.convert_to_float (audio.py:582, samples / 2^(bits-1)) followed by get_impulse gives: against the oracle on
+    the converted capture within 1e-12 of the peak, and exactly 2^-(bits-1) times the response of the raw integers."""
+    from zignal_amd.audio import Audio
+    taps = TAPS[N][0]
+    L = (1 << N) - 1
+    R = 3
+    bits = 8 * np.dtype(np_dt).itemsize
+    rng = np.random.default_rng(N * 31 + C)
+    seq = c_oracle.sequence(N, taps)
+    one = np.asarray(seq, dtype=np.float64).reshape(-1)
+    g = rng.standard_normal(8) * 0.2
+    cols = []
+    for c in range(C):
+        y = np.zeros(L)
+        for k, gk in enumerate(g):
+            y += gk * np.roll(one, 100 * c + k)
+        y = np.tile(y, R) + 1e-3 * rng.standard_normal(R * L)
+        cols.append(y / np.max(np.abs(y)) * 0.9)
+    a = Audio(fs=48000, initialdata=np.stack(cols, axis=1))
+    a.convert_to_integer(targetbits=bits)
+    x_int = a.samples
+    assert x_int.dtype == np_dt
+    m = _MLS_base(N, taps, device=0)
+    h = m.get_impulse_pcm(x_int if C > 1 else x_int[:, 0])
+    assert h.shape == (L, C) and h.dtype == np.float64
+    raw = m.get_impulses(x_int)
+    assert np.array_equal(h, raw * 2.0 ** -(bits - 1))
+    assert np.array_equal(m.get_impulses(x_int), raw)              # the scale does not stick to the plan
+    b = Audio(fs=48000, initialdata=x_int)
+    b.convert_to_float()
+    assert b.samples.dtype == np.float64 and np.array_equal(b.samples, x_int / 2.0 ** (bits - 1))
+    for c in sorted({0, C - 1}):
+        want = oracle_ir(N, taps, np.ascontiguousarray(b.samples[:, c:c + 1]), seq)
+        assert rel_err(h[:, c], want) <= TOL64
+    with pytest.raises(TypeError):
+        m.get_impulse_pcm(b.samples)

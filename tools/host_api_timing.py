@@ -35,3 +35,18 @@ for N, R in ((16, 2), (16, 5), (18, 2), (20, 2), (20, 17)):
     print("N=%d R=%d: zignal_amd get_impulse %.2f ms (%.1f M IR-samples/s), get_full_sequence %.2f ms, first plan+sequence %.0f ms | "
           "oracle get_impulse %.0f ms (%.2f M IR-samples/s) | x%.0f | max rel err %.1e"
           % (N, R, t_gpu * 1e3, L / t_gpu / 1e6, t_seq * 1e3, t_first * 1e3, t_cpu * 1e3, L / t_cpu / 1e6, t_cpu / t_gpu, err), flush=True)
+
+# raw int16 frames (sound card / wav) against the same capture converted to float64 on the host first
+for N, R, C in ((20, 17, 1), (18, 3, 64)):
+    taps = TAPS[N][0]
+    L = (1 << N) - 1
+    m = _MLS_base(N, taps)
+    rng = np.random.default_rng(N)
+    x16 = rng.integers(-20000, 20000, size=(R * L, C), dtype=np.int16)
+    m.get_impulse_pcm(x16)
+    t_pcm = best(lambda: m.get_impulse_pcm(x16))
+    t_conv = best(lambda: m.get_impulses(x16 / 32768.0))
+    xf = x16 / 32768.0
+    t_f64 = best(lambda: m.get_impulses(xf))
+    print("N=%d R=%d C=%d int16: get_impulse_pcm %.2f ms | convert on host + get_impulses %.2f ms | float64 already there %.2f ms"
+          % (N, R, C, t_pcm * 1e3, t_conv * 1e3, t_f64 * 1e3), flush=True)

@@ -47,6 +47,25 @@ class Audio(object):
     def copy(self):
         return Audio(fs=self.fs, initialdata=self.samples)
 
+    # -- sample formats (host side; the MLS path can take the integers directly: get_impulse_pcm) ----------
+    def convert_to_float(self, targetbits=64):
+        """Integers -> floats in [-1, 1): samples / 2^(sourcebits-1), in place (audio.py:565-589)."""
+        assert targetbits in (32, 64)
+        target = np.float32 if targetbits == 32 else np.float64
+        if np.issubdtype(self.samples.dtype, np.integer):
+            full_scale = 2 ** (8 * self.samples.itemsize - 1)
+            self.samples = np.array(self.samples / full_scale, dtype=target)
+        else:
+            self.samples = np.array(self.samples, dtype=target)
+
+    def convert_to_integer(self, targetbits=16):
+        """Floats in [-1, 1] -> signed integers: samples * (2^(targetbits-1) - 1), truncated, in place
+        (audio.py:534-563)."""
+        assert targetbits in (8, 16, 32, 64)
+        if not np.issubdtype(self.samples.dtype, np.floating):
+            raise NotImplementedError("TODO: implement scale int->int")
+        self.samples = np.array(self.samples * (2 ** (targetbits - 1) - 1), dtype='int%d' % targetbits)
+
     # -- per-channel statistics shown by __str__ -------------------------------------------------
     def _wide(self):
         s = self.samples

@@ -1,4 +1,5 @@
 // C ABI of libzmls.so (declarations and the reference methods they replace: include/zmls.h).
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -236,6 +237,13 @@ int zmls_plan_force_tile(zmls_plan *p, int cfg)
     return ZMLS_OK;
 }
 
+int zmls_plan_set_input_scale_log2(zmls_plan *p, int k)
+{
+    if (!p || k < 0 || k > 63) { set_error("input scale must be 2^k with 0 <= k <= 63"); return ZMLS_E_ARG; }
+    p->in_scale_log2 = k;
+    return ZMLS_OK;
+}
+
 int zmls_plan_info(const zmls_plan *p, int64_t info[16])
 {
     if (!p || !info) { set_error("null argument"); return ZMLS_E_ARG; }
@@ -333,6 +341,7 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
     a.row_stride = row_stride; a.ch_stride = ch_stride; a.n_ch = n_ch;
     a.gather = p->d_gather;
     a.h = d_h; a.out_row_stride = out_row_stride; a.out_ch_stride = out_ch_stride;
+    a.out_scale = ldexp(1.0 / (double)p->L, -p->in_scale_log2);
 
     if (single) {
         const int K = p->bits[0];

@@ -83,6 +83,7 @@ struct PassArgs {
     void *h;
     int64_t out_row_stride, out_ch_stride;
     const uint32_t *scatter;  // last pass's thread order (single: natural order)
+    double out_scale;         // 1/L, times 2^-k for raw PCM captures (zmls_plan_set_input_scale_log2)
 };
 
 // the launch sequence of one impulse-response batch (api.hip); ev/pass_ms null unless timed
@@ -147,5 +148,6 @@ struct zmls_plan {
     size_t host_call_bytes[2];
     int force_cfg;                // -1: choose per call; else a tile configuration (tests, tuning)
     int swizzle;                  // XCD-aware block mapping on/off (tuning)
+    int in_scale_log2;            // captures are raw integers with full scale 2^k: responses come out divided by 2^k
     int work_layout;              // 0: workspace slab-major, 1: row-major with slab-fastest block order in every pass
 };

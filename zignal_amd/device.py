@@ -126,12 +126,27 @@ class Plan:
         return q, m
 
     # -- impulse responses
-    def impulse_host(self, x):
-        """x: ndarray (R*L,) or (R*L, C), any strides; returns (L, C) of the plan dtype."""
+    def set_input_scale_log2(self, k):
+        """Captures handed to the impulse entry points are raw integers with full scale 2^k: responses come out
+        divided by 2^k (zmls_plan_set_input_scale_log2). 0: samples at face value."""
+        L.check(L.lib().zmls_plan_set_input_scale_log2(self._h, int(k)))
+
+    def impulse_host(self, x, pcm=False):
+        """x: ndarray (R*L,) or (R*L, C), any strides; returns (L, C) of the plan dtype.
+        pcm=True: x holds raw int16/int32 frames; the result is that of Audio.convert_to_float (audio.py:582)
+        followed by the same call, with the conversion done on the device."""
         x2, code, n_rows, n_ch, rs, cs = self._as_capture(x)
         h = np.empty((self.L, n_ch), dtype=self.np_dtype)
-        L.check(L.lib().zmls_impulse_host(self._h, x2.ctypes.data, code, n_rows, n_ch, rs, cs,
-                                          h.ctypes.data, n_ch, 1))
+        if pcm:
+            if code not in (L.ZMLS_I16, L.ZMLS_I32):
+                raise TypeError("raw PCM captures are int16 or int32, not %s" % x2.dtype)
+            self.set_input_scale_log2(8 * x2.dtype.itemsize - 1)
+        try:
+            L.check(L.lib().zmls_impulse_host(self._h, x2.ctypes.data, code, n_rows, n_ch, rs, cs,
+                                              h.ctypes.data, n_ch, 1))
+        finally:
+            if pcm:
+                self.set_input_scale_log2(0)
         return h
 
     @staticmethod

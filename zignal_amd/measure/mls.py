@@ -142,6 +142,18 @@ class _MLS_base(object):
         h = self._plan().impulse_host(x)
         return h.astype(np.float64, copy=False)
 
+    # ---- additive: raw sound-card / wav frames
+    def get_impulse_pcm(self, x):
+        """x: int16 or int32 frames (R*L,), (R*L, 1) or (R*L, C) as sndcard.PA.play_rec / a wav file deliver them
+        (sndcard.py:296-318, audio.py:1108-1123). Same result as Audio.convert_to_float (audio.py:565-589:
+        samples / 2^(bits-1)) followed by get_impulse / get_impulses, but the integers are what crosses PCIe
+        and the division is folded into the last kernel's scale (exact: a power of two)."""
+        assert isinstance(x, np.ndarray)
+        assert len(x) > self.L, "The first sequence will be thrown away"
+        if len(x) % self.L:
+            raise ValueError("number of frames %d is not a multiple of L=%d" % (len(x), self.L))
+        return self._plan().impulse_host(x, pcm=True).astype(np.float64, copy=False)
+
     # ---- additive: many channels at once (the reference is single-channel, mls.py:338-343)
     def get_impulses(self, x):
         """x: (R*L, C) -> (L, C): every column is treated as get_impulse treats its input."""
