@@ -169,3 +169,13 @@ def test_product_never_imports_the_oracle():
     code = "import sys; import zignal_amd.measure.mls; print('torch' in sys.modules, any(m.startswith('oracle') for m in sys.modules))"
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode().split()
     assert out == ["False", "False"]
+
+
+def test_argument_errors_need_no_device(lib):
+    """Null handles and out-of-range values are refused before anything touches a GPU."""
+    assert lib.zmls_plan_set_input_scale_log2(None, 15) == _lib.E_ARG
+    assert lib.zmls_dev_copy(0, None, None, 16, None) == _lib.E_ARG
+    assert lib.zmls_device_count(None) == _lib.E_ARG
+    assert lib.zmls_plan_info(None, None) == _lib.E_ARG
+    assert lib.zmls_plan_force_tile(None, 0) == _lib.E_ARG
+    assert b"" != _lib.last_error().encode()
