@@ -275,3 +275,17 @@ class MLS_simple(object):
     def plot_fft(self, plotname=None):
         assert hasattr(self, "_impulseresponse"), "call get_impulse(...) before trying to plot"
         self._impulseresponse.plot_fft(plotname=plotname, window='rectangular', normalise=False)
+
+
+if __name__ == '__main__':
+    # `python -m zignal_amd.measure.mls`: the loop-back demonstration of zignal's module (mls.py:469-491) - an
+    # MLS_simple measures itself, so the response is a unit impulse and its magnitude response is flat.
+    demo = MLS_simple(N=13, fs=96000, repeats=4)
+    print(repr(demo))
+    print(demo)
+    response = demo.get_impulse(demo.samples)
+    value, index = response.peak()
+    frq, mag = response.fft(window='rectangular', normalise=False)
+    print("loop-back impulse response: peak %.6f at sample %d; magnitude response %.2e .. %.2e dB" %
+          (value[0], index[0], mag[1:].min(), mag[1:].max()))
+    print('++ End of script ++')
