@@ -1,0 +1,58 @@
+"""The driver's contract with bench.py and __graft_entry__: one JSON line with the agreed fields on a GPU, a loud
+failure without one."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from zignal_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, timeout=300):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), cwd=ROOT, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_and_smoke_fail_loudly_without_a_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = run_bench("--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and r.stdout.strip() == "" and "no GPU" in r.stderr
+    code = "import __graft_entry__ as g; g.smoke()"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [(), ("--dtype", "f32"), ("--layout", "capture"), ("--mode", "period", "--cpu-seconds", "0")])
+def test_bench_prints_one_json_line_with_the_agreed_fields(extra):
+    r = run_bench("--order", "14", "--channels", "32", "--periods", "3", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", *extra)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d)
+    assert d["unit"] == "Gsamples/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == ("f32" if "f32" in extra else "f64")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    L = (1 << 14) - 1
+    assert abs(d["value"] - 32 * 3 * L / (d["ms_per_step"] * 1e-3) / 1e9) <= 1e-6 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and roof["achieved"] > 0
+    assert d["system_check_max_abs_err"] < (1e-4 if "f32" not in extra else 1e-3)
+    if "period" in extra:
+        assert d["cpu_baseline"] is None
+    else:
+        cpu = d["cpu_baseline"]
+        assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["unit"] == "Gsamples/s" and cpu["sample"]
+        assert d["parity_max_rel_err_vs_oracle"] <= (1e-12 if "f32" not in extra else 1e-5)
