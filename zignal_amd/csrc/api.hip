@@ -76,6 +76,18 @@ void free_plan_buffers(zmls_plan *p)
     }
 }
 
+// M in the order in which the last pass of tile configuration c holds its elements (2^N entries)
+int build_scatter_perm(zmls_plan *p, int c)
+{
+    const int np = (c == CFG_TALL) ? p->tall_npass : p->npass;
+    const int *bits = (c == CFG_TALL) ? p->tall_bits : p->bits;
+    if (np < 2 || p->d_scatter_perm[c]) return ZMLS_OK;
+    int b = 0;
+    for (int i = 0; i + 1 < np; ++i) b += bits[i];
+    ZHIP(hipMalloc((void **)&p->d_scatter_perm[c], ((size_t)1 << p->N) * 4));
+    return launch_scatter_perm(p->N, bits[np - 1], kCfg[c], b, p->d_scatter_nat, p->d_scatter_perm[c], 0);
+}
+
 int build_plan(zmls_plan *p)
 {
     const uint64_t n = 1ull << p->N;
@@ -114,13 +126,8 @@ int build_plan(zmls_plan *p)
     if (!(p->npass == 3 && p->tall_npass == 2)) p->tall_npass = 0;
     if (p->npass > 1) {
         for (int c = 0; c < CFG_COUNT; ++c) {
-            const int np = (c == CFG_TALL) ? p->tall_npass : p->npass;
-            const int *bits = (c == CFG_TALL) ? p->tall_bits : p->bits;
-            if (!np) continue;
-            int b = 0;
-            for (int i = 0; i + 1 < np; ++i) b += bits[i];
-            ZHIP(hipMalloc((void **)&p->d_scatter_perm[c], n * 4));
-            rc = launch_scatter_perm(p->N, bits[np - 1], kCfg[c], b, p->d_scatter_nat, p->d_scatter_perm[c], 0);
+            if (c == CFG_BIG) continue;                   // only ever used when forced: built by zmls_plan_force_tile
+            rc = build_scatter_perm(p, c);
             if (rc) return rc;
         }
     }
@@ -231,6 +238,12 @@ int zmls_plan_force_tile(zmls_plan *p, int cfg)
 {
     if (!p || cfg < -1 || (cfg >= 0 && (cfg & 0xFF) >= CFG_COUNT)) { set_error("tile configuration must be -1 (auto), 0 (small), 1 (big), 2 (mid) or 3 (tall)"); return ZMLS_E_ARG; }
     if (cfg >= 0 && (cfg & 0xFF) == CFG_TALL && !p->tall_npass) { set_error("the tall tile exists for orders 21 and 22 only"); return ZMLS_E_UNSUPPORTED; }
+    if (cfg >= 0 && (cfg & 0xFF) == CFG_BIG) {
+        int rc = use_device(p->device);
+        if (!rc) rc = build_scatter_perm(p, CFG_BIG);
+        if (rc) return rc;
+        ZHIP(hipDeviceSynchronize());                     // callers may launch on streams that do not wait for the null stream
+    }
     p->swizzle = (cfg >= 0 && (cfg & 0x100)) ? 0 : 1;     // +256: switch the XCD-aware block mapping off (tuning)
     p->work_layout = (cfg >= 0 && (cfg & 0x400)) ? 1 : 0; // +1024: row-major workspace (tuning)
     p->force_cfg = cfg < 0 ? -1 : (cfg & 0xFF);
@@ -370,6 +383,7 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
     }
     a.work = p->d_work;
     a.scatter = p->d_scatter_perm[cfg];
+    if (!a.scatter) { set_error("tile configuration %d has not been prepared for this plan", cfg); return ZMLS_E_UNSUPPORTED; }
     for (int64_t s0 = 0; s0 < n_slabs; s0 += cap) {
         const uint32_t ns = (uint32_t)((n_slabs - s0 < cap) ? n_slabs - s0 : cap);
         a.ch_first = s0 * CS;
