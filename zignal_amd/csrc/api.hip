@@ -336,7 +336,15 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
     // register-resident workgroups per CU); everything else, and every single-pass order, through the small one
     // (measured on the N=20, 512-channel, 16-period batch: small 19.3 ms, big 15.9 ms, mid 14.9 ms per step)
     int cfg = CFG_SMALL;
-    if (vec_in && vec_out && n_ch >= chans_per_slab(p, CFG_MID) && p->force_cfg != CFG_SMALL) cfg = p->tall_npass ? CFG_TALL : CFG_MID;
+    if (vec_in && vec_out && n_ch >= chans_per_slab(p, CFG_MID) && p->force_cfg != CFG_SMALL) {
+        // ... unless the batch is so small that the mid tile's grid (2^(N-10) macro tiles per 128-byte slab) would leave
+        // CUs idle: under 512 workgroups the small tile's four times finer grid is 10-20 % faster (N=16 x 64 channels:
+        // 25.6 against 31.7 us; N=14 x 256: 31.4 against 35.2 us; from N=18 x 64 = 1024 workgroups on, mid wins)
+        const int cs_mid = chans_per_slab(p, CFG_MID);
+        const uint64_t mid_grid = (uint64_t)((n_ch + cs_mid - 1) / cs_mid) << (p->N > 10 ? p->N - 10 : 0);
+        if (p->tall_npass) cfg = CFG_TALL;
+        else if (mid_grid >= 512 || p->force_cfg == CFG_MID) cfg = CFG_MID;
+    }
     if (p->force_cfg > CFG_SMALL) {
         if (!(vec_in && vec_out)) { set_error("the wide tiles need vector-aligned contiguous channels"); return ZMLS_E_ARG; }
         cfg = p->force_cfg;
