@@ -662,19 +662,28 @@ int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch,
         *ms_out = ms;
         return ZMLS_OK;
     };
-    // A placement can lose its speed when the candidates it was compared with are given back (seen about once in
-    // twelve searches: 12.6 ms before, 13.6 ms after, for the life of the buffer). So the winner is rated again after
-    // the others are freed, and if it no longer holds its time the search is repeated with it held as a reject.
+    // What the gather pass of this shape takes on a good placement: its bytes at the 5.75 TB/s the pass reaches on
+    // MI355X. Placements come in plateaus (headline: 12.5-12.7 ms, 13.3-13.6 ms, now and then 14.5+), so
+    // two candidates that agree can both sit on the upper one: the model tells a plateau from the floor.
+    const double model_ms = ((double)periods * (double)is + (double)dtype_size(p->dtype)) * (double)p->L * (double)n_ch / 5.75e9;
+    auto at_floor = [&](float ms) { return ms <= (float)(model_ms * 1.035); };
+    auto floor_in_reach = [&](float ms) { return ms <= (float)(model_ms * 1.15); };     // shapes the model fits at all
+    // A placement can also lose its speed when the candidates it was compared with are given back (seen about once
+    // in twelve searches: 12.6 ms before, 13.6 ms after, for the life of the buffer). So the winner is rated again
+    // after the others are freed; if it no longer holds its time, or sits on a plateau above a floor that is in
+    // reach, the search is repeated with it kept allocated (so that its memory is not handed out again).
+    void *keep = nullptr;
+    float keep_ms = 0.f;
     for (int round = 0; round < 3 && !rc; ++round) {
         float second_ms = 0.f;
-        void *held = best;                                // the degraded winner of the round before, if any
+        int rated = 0;
         best = nullptr; best_ms = 0.f;
         for (int t = 0; t < tries; ++t) {
             void *cand = nullptr;
             hipError_t e = hipMalloc(&cand, bytes);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
-                if (!best && !held) rc = hip_fail(e, "hipMalloc(capture)");
+                if (!best && !keep) rc = hip_fail(e, "hipMalloc(capture)");
                 break;                                    // memory is full of candidates: settle for the best so far
             }
             float ms = 0.f;
@@ -682,6 +691,7 @@ int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch,
             if (e != hipSuccess) rc = hip_fail(e, "capture placement probe");
             if (!rc) rc = rate(cand, &ms);
             if (rc) { (void)hipFree(cand); break; }
+            ++rated;
             if (!best || ms < best_ms) {
                 if (best) reject(best);
                 second_ms = best ? best_ms : 0.f;
@@ -690,23 +700,31 @@ int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch,
                 if (second_ms == 0.f || ms < second_ms) second_ms = ms;
                 reject(cand);
             }
-            // two candidates within 2 % of each other at the top: that is the floor, stop looking
-            if (second_ms > 0.f && second_ms <= best_ms * 1.02f) break;
+            if (at_floor(best_ms)) break;
+            // two candidates within 2 % of each other at the top: a plateau. Where the model says a lower one is in
+            // reach, a third candidate has to agree before it is taken for the floor
+            if (second_ms > 0.f && second_ms <= best_ms * 1.02f && (!floor_in_reach(best_ms) || rated >= 3)) break;
         }
         for (int i = 0; i < 2; ++i) {
             if (rejected[i]) (void)hipFree(rejected[i]);
             rejected[i] = nullptr;
         }
-        if (rc) break;
-        if (!best) { best = held; held = nullptr; break; }      // nothing new could be allocated: keep what there is
-        if (held) (void)hipFree(held);
+        if (rc) { if (best) (void)hipFree(best); best = nullptr; break; }
+        if (!best) break;                                  // nothing new could be allocated: keep what there is
+        if (keep && keep_ms <= best_ms) { (void)hipFree(best); }
+        else {
+            if (keep) (void)hipFree(keep);
+            keep = best; keep_ms = best_ms;
+        }
+        best = nullptr;
         float again = 0.f;
-        rc = rate(best, &again);
+        rc = rate(keep, &again);
         if (rc) break;
-        const bool holds = again <= best_ms * 1.03f;
-        best_ms = again;
-        if (holds) break;
+        const bool holds = again <= keep_ms * 1.03f;
+        keep_ms = again;
+        if (holds && (at_floor(again) || !floor_in_reach(again))) break;
     }
+    best = keep; best_ms = keep_ms;
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
     if (rc) { if (best) (void)hipFree(best); return rc; }
