@@ -662,11 +662,14 @@ int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch,
         *ms_out = ms;
         return ZMLS_OK;
     };
-    // What the gather pass of this shape takes on a good placement: its bytes at the 5.75 TB/s the pass reaches on
-    // MI355X. Placements come in plateaus (headline: 12.5-12.7 ms, 13.3-13.6 ms, now and then 14.5+), so
-    // two candidates that agree can both sit on the upper one: the model tells a plateau from the floor.
-    const double model_ms = ((double)periods * (double)is + (double)dtype_size(p->dtype)) * (double)p->L * (double)n_ch / 5.75e9;
-    auto at_floor = [&](float ms) { return ms <= (float)(model_ms * 1.035); };
+    // What the gather pass of this shape takes on a good placement: the capture read at 5.85 TB/s plus the intermediate
+    // written at 5.2 TB/s, the rates the pass reaches on MI355X (fits 12.5 ms at N=20 x 512 x 16 periods, 3.1 ms at
+    // N=20 x 1024 x 1, 12.5 ms at N=24 x 256 x 1). Placements come in plateaus (headline: 12.5-12.7 ms,
+    // 13.3-13.6 ms, now and then 14.5+), so two candidates that agree can both sit on the upper one: the model tells a
+    // plateau from the floor.
+    const double cells = (double)p->L * (double)n_ch;
+    const double model_ms = cells * (double)periods * (double)is / 5.85e9 + cells * (double)dtype_size(p->dtype) / 5.2e9;
+    auto at_floor = [&](float ms) { return ms <= (float)(model_ms * 1.025); };
     auto floor_in_reach = [&](float ms) { return ms <= (float)(model_ms * 1.15); };     // shapes the model fits at all
     // A placement can also lose its speed when the candidates it was compared with are given back (seen about once
     // in twelve searches: 12.6 ms before, 13.6 ms after, for the life of the buffer). So the winner is rated again
