@@ -56,3 +56,19 @@ def test_bench_prints_one_json_line_with_the_agreed_fields(extra):
         cpu = d["cpu_baseline"]
         assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["unit"] == "Gsamples/s" and cpu["sample"]
         assert d["parity_max_rel_err_vs_oracle"] <= (1e-12 if "f32" not in extra else 1e-5)
+
+
+@pytest.mark.gpu
+def test_two_ranks_print_one_json_line_too():
+    """The driver's N > 1 launch (torch.distributed.run, one rank per GPU; both ranks share the card on a one-GPU box):
+    rank 0 alone prints, and nothing else (gloo's connection report, RCCL's banner) reaches stdout."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--order", "14", "--channels", "32",
+                        "--periods", "3", "--steps", "3", "--warmup", "1"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    L = (1 << 14) - 1
+    assert abs(d["value"] - 2 * 32 * 3 * L / (d["ms_per_step"] * 1e-3) / 1e9) <= 1e-6 * d["value"]
