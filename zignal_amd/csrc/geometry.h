@@ -57,7 +57,11 @@ struct RoundGeo {
     int nthr;
 };
 
-ZHD constexpr int num_rounds(int K, TileCfg c) { return (K + c.rb - 1) / c.rb; }
+// A pass of 2*RB+1 bits gets no third round for its last bit: that butterfly is folded into the read side of the LDS
+// exchange before round 1 (every thread reads both partners along the bit; the stages of a WHT commute). It saves a
+// whole exchange for one more LDS read per element. -1: the pass has no such bit.
+ZHD constexpr int fused_bit(int K, TileCfg c) { return K == 2 * c.rb + 1 ? K - 1 : -1; }
+ZHD constexpr int num_rounds(int K, TileCfg c) { return fused_bit(K, c) >= 0 ? 2 : (K + c.rb - 1) / c.rb; }
 ZHD constexpr int log2_tiles(int K, TileCfg c) { return c.logv - c.lu - K; }
 
 // first_pass: the pass works on bit offset 0, its tiles are contiguous runs of rows, and the

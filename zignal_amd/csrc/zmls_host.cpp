@@ -124,8 +124,17 @@ int zmls_host_geometry_selfcheck(int K, int cfg_id, int first_pass)
             if (s >= slots || slot_owner[s] != -1) { set_error("LDS slot clash at l=%u u=%d", l, u); return -100; }
             slot_owner[s] = (int)l;
         }
+    int butterflied[16] = {0};
     for (int r = 0; r < num_rounds(K, C); ++r) {
         const RoundGeo g = make_round(K, C, first_pass != 0, r);
+        for (int j = 0; j < g.nbf; ++j) butterflied[g.regbit[j]]++;
+        if (r == num_rounds(K, C) - 1 && fused_bit(K, C) >= 0) {
+            // the bit folded into the exchange before the last round must be held by the threads there, not in registers
+            bool on_thread = false;
+            for (int q = 0; q < g.nthr; ++q) on_thread |= g.thrbit[q] == fused_bit(K, C);
+            if (!on_thread) { set_error("fused bit %d is not a thread bit of the last round", fused_bit(K, C)); return -106; }
+            butterflied[fused_bit(K, C)]++;
+        }
         if (g.nthr != NB - C.rb) { set_error("round %d: %d thread bits, expected %d", r, g.nthr, NB - C.rb); return -101; }
         std::vector<int> seen(n_log, 0);
         for (uint32_t tlog = 0; tlog < (uint32_t)(cfg_threads(C) >> C.lu); ++tlog)
@@ -140,6 +149,8 @@ int zmls_host_geometry_selfcheck(int K, int cfg_id, int first_pass)
         for (int j = 0; j < g.nbf; ++j)
             if (g.regbit[j] != C.rb * r + j) { set_error("round %d: register bit %d carries logical bit %d", r, j, g.regbit[j]); return -104; }
     }
+    for (int q = 0; q < NB; ++q)
+        if (butterflied[q] != (q < K ? 1 : 0)) { set_error("logical bit %d is butterflied %d times", q, butterflied[q]); return -107; }
     // rows of a pass at bit offset b: every row of the 2^(K+LT+b')-row neighbourhood exactly once
     const int LT = log2_tiles(K, C);
     for (int b = 0; b <= (first_pass ? 0 : 6); ++b) {
