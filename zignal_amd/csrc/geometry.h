@@ -9,7 +9,7 @@
 // row bits; tiles of a macro tile are independent (they only share the workgroup).
 //
 // Every thread keeps 2^RB vectors in registers (2^(LOGV-RB) threads). A pass is ceil(K/RB)
-// ROUNDS; round r butterflies row bits [RB*r, min(RB*r+RB, K)) entirely in registers, and between
+// ROUNDS (two for K = 2*RB+1, see fused_bit); round r butterflies row bits [RB*r, min(RB*r+RB, K)) entirely in registers, and between
 // rounds the macro tile is exchanged through LDS. For each round the LOGV-LU "logical bits" (row
 // bits 0..K-1, then tile bits K..K+LT-1) are split into RB register-index bits and the thread bits.
 //
