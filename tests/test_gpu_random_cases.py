@@ -21,7 +21,7 @@ def cases():
     rng = np.random.default_rng(20261110)
     out = []
     for i in range(60):
-        N = int(rng.choice([6, 9, 10, 11, 12, 13, 14, 15, 21]))
+        N = int(rng.choice([6, 9, 10, 11, 12, 13, 14, 15, 18, 19, 21]))
         big = N >= 15
         C = int(rng.choice([1, 2, 3, 16, 32]) if big else rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 24, 31, 32, 33, 48, 70]))
         R = int(rng.choice([2, 3]) if big else rng.choice([2, 3, 4, 6, 8]))
