@@ -418,3 +418,44 @@ def test_raw_pcm_captures_equal_convert_to_float_then_get_impulse(N, C, np_dt):
         assert rel_err(h[:, c], want) <= TOL64
     with pytest.raises(TypeError):
         m.get_impulse_pcm(b.samples)
+
+
+@pytest.mark.parametrize("N,dtype", [(2, "f64"), (3, "f64"), (4, "f64"), (5, "f64"), (6, "f64"), (7, "f32"), (8, "f64"), (9, "f64"),
+                                      (10, "f64"), (10, "f32"), (6, "f32")])
+def test_single_pass_orders_in_the_register_tile(N, dtype):
+    """Orders up to 10 are one pass. Wide aligned batches take it in the mid tile (whole transforms of 2^(10-N) slabs of
+    16 f64 / 32 f32 channels per workgroup, 16-byte vectors); channels that do not fill a workgroup's set of slabs, and
+    everything else, go through the small tile's element kernel. Both must agree to round-off and with the oracle."""
+    taps = TAPS[N][0] if N in TAPS else (2, 1)          # zignal's table starts at N = 3
+    L = (1 << N) - 1
+    R = 4
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    p = plan(N, taps, dtype)
+    per_wg = p.info()["channels_per_slab_mid"] << (10 - N)
+    tol_pair = 1e-14 if dtype == "f64" else 1e-5
+    for C in (per_wg, 3 * per_wg + 6 * (2 if dtype == "f64" else 4), per_wg // 2 if per_wg >= 64 else 2 * per_wg):
+        if C * R * L * 8 > (1 << 28):
+            continue
+        rng = np.random.default_rng(N * 7 + C)
+        x = rng.standard_normal((R * L, C)).astype(np_dt)
+        p.force_tile(2)
+        h_mid = p.impulse_host(x)
+        p.force_tile(0)
+        h_small = p.impulse_host(x)
+        p.force_tile(-1)
+        assert rel_err(h_mid, h_small.astype(np.float64)) <= tol_pair, (N, C)
+        ref = c_oracle.sequence(N, taps)
+        for c in sorted({0, C // 2, C - 1}):
+            want = oracle_ir(N, taps, np.ascontiguousarray(x[:, c:c + 1]).astype(np.float64), ref)
+            assert rel_err(h_mid[:, c], want) <= (TOL64 if dtype == "f64" else TOL32), (N, C, c)
+    # enough channels for 512 workgroups: the mid tile without being forced; an odd period count exercises the exact mean
+    if N >= 7:
+        C = 512 * per_wg
+        x = np.random.default_rng(N).standard_normal((3 * L, C)).astype(np_dt)
+        h_auto = p.impulse_host(x)
+        p.force_tile(0)
+        h_small = p.impulse_host(x[:, :64])
+        p.force_tile(2)
+        assert np.array_equal(p.impulse_host(x), h_auto)
+        p.force_tile(-1)
+        assert rel_err(h_auto[:, :64], h_small.astype(np.float64)) <= tol_pair

@@ -327,21 +327,23 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
     const size_t ts = dtype_size(p->dtype);
     const int E = (int)(kVecBytes / ts);
     const bool single = p->npass == 1;
-    const bool vec_in = !single && in_dtype == p->dtype && ch_stride == 1 && (row_stride * (int64_t)ts) % kVecBytes == 0 &&
+    const bool vec_in = in_dtype == p->dtype && ch_stride == 1 && (row_stride * (int64_t)ts) % kVecBytes == 0 &&
                         ((uintptr_t)d_x % kVecBytes) == 0 && n_ch % E == 0;
-    const bool vec_out = !single && out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 &&
+    const bool vec_out = out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 &&
                          ((uintptr_t)d_h % kVecBytes) == 0 && n_ch % E == 0;
     auto launch = (p->dtype == ZMLS_F64) ? launch_pass_f64 : launch_pass_f32;
     // wide vector-aligned channel blocks stream through the mid tile (128-byte row segments, two
-    // register-resident workgroups per CU); everything else, and every single-pass order, through the small one
-    // (measured on the N=20, 512-channel, 16-period batch: small 19.3 ms, big 15.9 ms, mid 14.9 ms per step)
+    // register-resident workgroups per CU); everything else through the small one
+    // (measured on the N=20, 512-channel, 16-period batch: small 19.3 ms, big 15.9 ms, mid 14.9 ms per step).
+    // Single-pass orders (N <= 10: the whole transform of 2^(10-N) slabs in one mid tile) follow the same rule.
     int cfg = CFG_SMALL;
     if (vec_in && vec_out && n_ch >= chans_per_slab(p, CFG_MID) && p->force_cfg != CFG_SMALL) {
         // ... unless the batch is so small that the mid tile's grid (2^(N-10) macro tiles per 128-byte slab) would leave
         // CUs idle: under 512 workgroups the small tile's four times finer grid is 10-20 % faster (N=16 x 64 channels:
         // 25.6 against 31.7 us; N=14 x 256: 31.4 against 35.2 us; from N=18 x 64 = 1024 workgroups on, mid wins)
         const int cs_mid = chans_per_slab(p, CFG_MID);
-        const uint64_t mid_grid = (uint64_t)((n_ch + cs_mid - 1) / cs_mid) << (p->N > 10 ? p->N - 10 : 0);
+        const uint64_t mid_slabs = (uint64_t)((n_ch + cs_mid - 1) / cs_mid);
+        const uint64_t mid_grid = p->N > 10 ? mid_slabs << (p->N - 10) : (mid_slabs + (1u << (10 - p->N)) - 1) >> (10 - p->N);
         if (p->tall_npass) cfg = CFG_TALL;
         else if (mid_grid >= 512 || p->force_cfg == CFG_MID) cfg = CFG_MID;
     }
@@ -368,12 +370,29 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
         const int K = p->bits[0];
         const int LT = log2_tiles(K, tc);
         a.single = 1; a.b = 0; a.n_macro = 1;
-        a.n_slab_groups = (uint32_t)((n_slabs + (1 << LT) - 1) >> LT);
-        a.ch_first = 0;
         a.scatter = p->d_scatter_nat;
         if (ev) ZHIP(hipEventRecord(ev[0], st));
-        rc = launch(cfg, K, IN_GATHER_ELEM, OUT_SCATTER_ELEM, a, st);
-        if (rc) return rc;
+        int64_t done = 0;
+        if (cfg != CFG_SMALL) {
+            // the mid tile holds the whole transforms of 2^LT slabs in registers and moves 16-byte vectors; it is launched
+            // on whole macro tiles only, the channels left over go through the small tile's element kernel below
+            const int64_t per_wg = (int64_t)CS << LT;
+            a.ch_first = 0;
+            a.n_slab_groups = (uint32_t)(n_ch / per_wg);
+            if (a.n_slab_groups) {
+                rc = launch(cfg, K, IN_GATHER_VEC, OUT_SCATTER_VEC, a, st);
+                if (rc) return rc;
+            }
+            done = (int64_t)a.n_slab_groups * per_wg;
+        }
+        if (done < n_ch) {
+            const int cs_small = chans_per_slab(p, CFG_SMALL), lt_small = log2_tiles(K, kCfg[CFG_SMALL]);
+            const int64_t slabs = (n_ch - done + cs_small - 1) / cs_small;
+            a.ch_first = done;
+            a.n_slab_groups = (uint32_t)((slabs + (1 << lt_small) - 1) >> lt_small);
+            rc = launch(CFG_SMALL, K, IN_GATHER_ELEM, OUT_SCATTER_ELEM, a, st);
+            if (rc) return rc;
+        }
         if (ev) {
             float ms = 0.f;
             ZHIP(hipEventRecord(ev[1], st));
