@@ -343,9 +343,12 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
         // 25.6 against 31.7 us; N=14 x 256: 31.4 against 35.2 us; from N=18 x 64 = 1024 workgroups on, mid wins)
         const int cs_mid = chans_per_slab(p, CFG_MID);
         const uint64_t mid_slabs = (uint64_t)((n_ch + cs_mid - 1) / cs_mid);
-        const uint64_t mid_grid = p->N > 10 ? mid_slabs << (p->N - 10) : (mid_slabs + (1u << (10 - p->N)) - 1) >> (10 - p->N);
+        const uint64_t mid_grid = p->N > 10 ? mid_slabs << (p->N - 10) : mid_slabs >> (10 - p->N);     // single pass: whole workgroups
         if (p->tall_npass) cfg = CFG_TALL;
         else if (mid_grid >= 512 || p->force_cfg == CFG_MID) cfg = CFG_MID;
+        // single-pass orders: the vector kernel wins at every size that fills one workgroup's set of slabs (N=10 x 256
+        // channels x 4 periods: 12 against 29 us, x 4096: 32 against 57 us; N=8 x 1024: 12 against 28 us)
+        else if (single && mid_grid >= 1) cfg = CFG_MID;
     }
     if (p->force_cfg > CFG_SMALL) {
         if (!(vec_in && vec_out)) { set_error("the wide tiles need vector-aligned contiguous channels"); return ZMLS_E_ARG; }
