@@ -107,6 +107,21 @@ int zmls_sequence_device(zmls_plan *p, void *d_out, int dtype, int64_t repeats, 
 int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch,
                         int64_t row_stride, int64_t ch_stride,
                         void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
+/* The same launch sequence for callers that cannot allocate. No counterpart in the reference: it is for code under
+ * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc. The intermediate between the FWHT
+ * passes lives in a static device array of ZMLS_STATIC_WORKSPACE_BYTES inside the library (every GPU the library
+ * runs on holds it until the process ends) instead of the workspace zmls_plan_reserve allocates, so a plan that
+ * never reserved anything can be used; the batch runs in chunks of as many channel slabs as the array holds.
+ * Orders above ZMLS_STATIC_MAX_ORDER (one slab of the intermediate no longer fits) are refused with
+ * ZMLS_E_WORKSPACE. Captures in any layout and input type are accepted; those that are not 16-byte-aligned
+ * (frames, channels) arrays of the plan's dtype go one element per lane (the layout adapters need allocated
+ * staging). Calls neither hipMalloc/hipFree nor synchronises. All calls on one GPU share the array: calls that
+ * overlap on one GPU (two streams, two threads) race; calls in stream order do not. */
+#define ZMLS_STATIC_WORKSPACE_BYTES (144u << 20)
+#define ZMLS_STATIC_MAX_ORDER 21
+int zmls_impulse_device_static(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch,
+                               int64_t row_stride, int64_t ch_stride,
+                               void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
 /* profiling variant (bench.py): same launches with a HIP event either side of every pass kernel on
  * `hip_stream`; synchronises and returns the milliseconds of pass i in pass_ms[i] (summed over channel
  * chunks). Creates and destroys its events: not for timed or captured regions. */

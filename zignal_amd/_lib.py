@@ -39,6 +39,7 @@ SIGNATURES = {
     "zmls_sequence_f64": [c_vp, c_vp, c_i64],
     "zmls_sequence_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_vp],
     "zmls_impulse_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],
+    "zmls_impulse_device_static": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],
     "zmls_impulse_device_timed": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp,
                                   ctypes.POINTER(ctypes.c_float)],
     "zmls_impulse_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64],

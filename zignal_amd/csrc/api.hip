@@ -162,6 +162,13 @@ int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int
     if (rc) return rc;
     rc = use_device(device);
     if (rc) return rc;
+    {
+        // set-up for zmls_impulse_device_static: this device's address of the static workspace, so that the
+        // launch path itself never has to ask the runtime for it
+        void *ws = nullptr;
+        rc = static_workspace(device, &ws, nullptr);
+        if (rc) return rc;
+    }
     zmls_plan *p = (zmls_plan *)calloc(1, sizeof(zmls_plan));
     if (!p) { set_error("out of host memory"); return ZMLS_E_ARG; }
     p->N = N;
@@ -311,11 +318,16 @@ int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
 
 namespace zmls {
 // the launch sequence of the passes on buffers as they are (no layout adapters)
-static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
-                        int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
-                        int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev /* 2 per pass, or null */,
-                        float *pass_ms /* accumulated, or null */, int gather_pass_only /* placement probe: stop after pass 1 */)
+// `work` / `work_bytes`: the intermediate between the passes; the plan's own workspace unless the caller brings another
+// (static_ws.hip), in which case a tile configuration whose slab does not fit gives way to the next narrower one.
+int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
+               int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
+               int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev /* 2 per pass, or null */,
+               float *pass_ms /* accumulated, or null */, int gather_pass_only /* placement probe: stop after pass 1 */,
+               void *work, size_t work_bytes)
 {
+    const bool own_work = work == nullptr;
+    if (own_work) { work = p ? p->d_work : nullptr; work_bytes = p ? p->work_bytes : 0; }
     if (!p || !d_x || (!d_h && !gather_pass_only)) { set_error("null argument"); return ZMLS_E_ARG; }
     if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
     if (n_ch < 1) { set_error("need at least one channel"); return ZMLS_E_ARG; }
@@ -353,6 +365,9 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
     if (p->force_cfg > CFG_SMALL) {
         if (!(vec_in && vec_out)) { set_error("the wide tiles need vector-aligned contiguous channels"); return ZMLS_E_ARG; }
         cfg = p->force_cfg;
+    } else if (!own_work && !single) {
+        if (cfg == CFG_TALL && work_bytes < slab_bytes(p, CFG_TALL)) cfg = CFG_MID;
+        if (cfg == CFG_MID && work_bytes < slab_bytes(p, CFG_MID)) cfg = CFG_SMALL;
     }
     const TileCfg tc = kCfg[cfg];
     const int npass = (cfg == CFG_TALL) ? p->tall_npass : p->npass;
@@ -406,12 +421,13 @@ static int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t perio
         return ZMLS_OK;
     }
 
-    const int64_t cap = (int64_t)(p->work_bytes / slab_bytes(p, cfg));
+    const int64_t cap = (int64_t)(work_bytes / slab_bytes(p, cfg));
     if (cap < 1) {
-        set_error("plan workspace (%zu bytes) holds no channel slab (%zu bytes each): call zmls_plan_reserve first", p->work_bytes, slab_bytes(p, cfg));
+        if (own_work) set_error("plan workspace (%zu bytes) holds no channel slab (%zu bytes each): call zmls_plan_reserve first", work_bytes, slab_bytes(p, cfg));
+        else set_error("order %d needs %zu bytes of workspace for one channel slab; the caller's workspace holds %zu", p->N, slab_bytes(p, cfg), work_bytes);
         return ZMLS_E_WORKSPACE;
     }
-    a.work = p->d_work;
+    a.work = work;
     a.scatter = p->d_scatter_perm[cfg];
     if (!a.scatter) { set_error("tile configuration %d has not been prepared for this plan", cfg); return ZMLS_E_UNSUPPORTED; }
     for (int64_t s0 = 0; s0 < n_slabs; s0 += cap) {
@@ -480,7 +496,7 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
     const bool out_cm = multi && !vec_out && out_row_stride == 1 && cc >= E;
     if (!in_cm && !in_fm && !out_cm)
         return run_passes(p, d_x, in_dtype, periods, skip_periods, divisor, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride,
-                          st, ev, pass_ms, gather_pass_only);
+                          st, ev, pass_ms, gather_pass_only, nullptr, 0);
     int rc = use_device(p->device);
     if (rc) return rc;
     for (int64_t c0 = 0; c0 < n_ch; c0 += cc) {
@@ -500,7 +516,7 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
         void *dst = (char *)d_h + (size_t)(c0 * out_ch_stride) * ts;
         int64_t dst_rs = out_row_stride, dst_cs = out_ch_stride;
         if (out_cm) { dst = p->d_stage[1]; dst_rs = Cs; dst_cs = 1; }
-        rc = run_passes(p, src, src_dtype, src_periods, src_skip, divisor, n_pass, src_rs, src_cs, dst, dst_rs, dst_cs, st, ev, pass_ms, 0);
+        rc = run_passes(p, src, src_dtype, src_periods, src_skip, divisor, n_pass, src_rs, src_cs, dst, dst_rs, dst_cs, st, ev, pass_ms, 0, nullptr, 0);
         if (rc) return rc;
         if (out_cm) {
             rc = launch_transpose_out(p->d_stage[1], p->dtype, p->L, Cs, n, (char *)d_h + (size_t)(c0 * out_ch_stride) * ts, out_ch_stride, st);
@@ -511,7 +527,7 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
 }
 } // namespace zmls
 
-namespace {
+namespace zmls {
 // a capture of R >= 2 periods: the first is thrown away, the rest are averaged (mls.py:284-306, 322-323)
 int capture_periods(const zmls_plan *p, int64_t n_rows, int64_t *periods)
 {
@@ -522,7 +538,7 @@ int capture_periods(const zmls_plan *p, int64_t n_rows, int64_t *periods)
     if (*periods > 0x7FFFFFFF) { set_error("too many periods"); return ZMLS_E_ARG; }
     return ZMLS_OK;
 }
-} // namespace
+} // namespace zmls
 
 extern "C" {
 

@@ -90,6 +90,14 @@ struct PassArgs {
 int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
                         int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
                         int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms, int gather_pass_only);
+// the passes on buffers as they are (no layout adapters); work = null: the plan's own workspace
+int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
+               int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
+               int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms, int gather_pass_only,
+               void *work, size_t work_bytes);
+int capture_periods(const zmls_plan *p, int64_t n_rows, int64_t *periods);
+// the library's static device workspace (static_ws.hip): resolved once per device, at plan creation
+int static_workspace(int device, void **ptr, size_t *bytes);
 size_t dtype_size(int dt);
 int use_device(int device);
 hipError_t settled_malloc(void **ptr, size_t bytes);
