@@ -13,15 +13,22 @@ collective, weak scaling); torch.distributed (gloo, CPU tensors) is used only fo
 and the max-over-ranks of the step time. The library itself has no PyTorch dependency.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     : algorithmic bytes of one step / device time of its kernels (HIP events), vs 8 TB/s
+  roofline     : algorithmic bytes of one step / device time of its kernels (HIP events), vs 8 TB/s,
+                 beside what hand-written stream kernels read and copy on this GPU in the same run
   cpu_baseline : the oracle (Python restatement of the reference) timed on this box's host cores
-                 on a bounded sample of the same workload.
+                 on a bounded sample of the same workload
+  configs      : (N=1, default workload) the other BASELINE.json configurations that fit one GPU, a few
+                 steps each with their own roofline, parity against the oracle and CPU baseline
+  period_mode  : (N>1) the same batch with the PERIODS striped over the GPUs instead of the channels:
+                 partial period sums reduce-scattered with RCCL over xGMI (BASELINE config 3's
+                 "RCCL reduce"); `value` stays the channel-sharded (collective-free) number.
 """
 import argparse
 import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -33,8 +40,11 @@ from zignal_amd import _lib, multi  # noqa: E402
 from zignal_amd.device import DeviceBuffer, Plan, Timer, download_channel, sync  # noqa: E402
 from zignal_amd.measure.mlstaps import TAPS  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the guide's measured copy rate
 SEED = 0x5A17
+CODE = {"f64": _lib.ZMLS_F64, "f32": _lib.ZMLS_F32}
+ESIZE = {"f64": 8, "f32": 4}
+TOL = {"f64": 1e-12, "f32": 1e-5}      # BASELINE.json north_star: max-abs error relative to peak
 
 
 def parse():
@@ -57,7 +67,51 @@ def parse():
     ap.add_argument("--reserve-channels", type=int, default=0, help="workspace for this many channels only (the batch then runs in channel chunks; tuning)")
     ap.add_argument("--plain-alloc", action="store_true", help="allocate the capture with one plain hipMalloc (no placement probing)")
     ap.add_argument("--tile", type=int, default=-1, help="force a tile configuration (tuning): 0 small, 1 big, 2 mid, 3 tall, +256 no XCD swizzle")
+    ap.add_argument("--configs", default="auto", choices=["auto", "all", "none"],
+                    help="the other BASELINE configs after the headline (N=1 only): auto = when the headline workload is the default one")
+    ap.add_argument("--period-leg", default="auto", choices=["auto", "none"],
+                    help="N>1: also run the period-sharded RCCL leg after the channel-mode timing (auto) or not (none)")
+    ap.add_argument("--period-leg-steps", type=int, default=3)
+    ap.add_argument("--period-leg-timeout", type=float, default=240.0, help="seconds before the RCCL leg is given up (its result is then an error entry)")
     return ap.parse_args()
+
+
+class quiet_stdout:
+    """gloo and RCCL report on stdout (C++ side); stdout carries the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.keep = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.keep, 1)
+        os.close(self.keep)
+
+
+def oracle_parity(plan, d_x, d_h, n_rows, C, rs, cs, ors, ocs, code, channels, ref=None, timed_as_shipped=0, budget_s=1e9):
+    """GPU responses of `channels` against the oracle on the very captures pulled back from the device. The first
+    `timed_as_shipped` of them are run as the reference ships the path (stimulus regenerated by the per-bit Python loop
+    on every call, zignal/measure/mls.py:207) and timed; the rest use the stimulus made once by the C half of the oracle.
+    Returns (worst relative error, seconds of the as-shipped calls, number of them)."""
+    from oracle import c_oracle, mls_oracle
+    N, L, taps = plan.N, plan.L, plan.taps
+    worst, t_used, n_timed = 0.0, 0.0, 0
+    for i, c in enumerate(channels):
+        x = download_channel(plan.device, d_x.ptr, code, n_rows, rs, cs, c).astype(np.float64).reshape(-1, 1)
+        h_gpu = download_channel(plan.device, d_h.ptr, plan.dtype_code, L, ors, ocs, c).astype(np.float64)
+        if i < timed_as_shipped and t_used < budget_s:
+            t0 = time.perf_counter()
+            h_cpu = mls_oracle.get_impulse(N, taps, x)[:, 0]
+            t_used += time.perf_counter() - t0
+            n_timed += 1
+        else:
+            if ref is None:
+                ref = c_oracle.sequence(N, taps)
+            h_cpu = mls_oracle.get_impulse(N, taps, x, ref=ref)[:, 0]
+        worst = max(worst, float(np.max(np.abs(h_gpu - h_cpu)) / np.max(np.abs(h_cpu))))
+    return worst, t_used, n_timed
 
 
 def cpu_baseline_and_check(args, plan, d_x, d_h, n_rows, C, rs, cs, ors, ocs, dtype_code):
@@ -66,7 +120,6 @@ def cpu_baseline_and_check(args, plan, d_x, d_h, n_rows, C, rs, cs, ors, ocs, dt
     and checks the GPU result of those channels against it."""
     from oracle import mls_oracle
     N, L, taps = plan.N, plan.L, plan.taps
-    np_dt = _lib.NP_OF[dtype_code]
     t_used, n_done, worst = 0.0, 0, 0.0
     chans = [0, C // 2, C - 1] + [(7 + 37 * i) % C for i in range(C)]     # spread over the batch until the budget is used
     for c in chans:
@@ -100,7 +153,7 @@ def cpu_baseline_and_check(args, plan, d_x, d_h, n_rows, C, rs, cs, ors, ocs, dt
                   % (n_done, C, N, args.periods, t_used),
         "ir_gsamples_per_s": n_done * L / t_used / 1e9,
         "sequence_cached": cached,
-    }, worst, np_dt
+    }, worst
 
 
 def cpu_all_cores(N, taps, R, seconds):
@@ -129,31 +182,35 @@ def cpu_all_cores(N, taps, R, seconds):
     return calls * (R - 1) * L / longest, P, calls, longest
 
 
-def copy_calibration(dev, d_buf):
-    """Same-run calibration of what this GPU streams: a device-to-device copy inside `d_buf` (first part onto the
-    last part; it overwrites data, so it runs after every check). Returns GB/s counting bytes read + written."""
-    n = min(d_buf.nbytes // 2, 8 << 30) // 4096 * 4096
+def stream_calibration(dev, d_buf):
+    """What this GPU streams in this very run, with hand-written 16-byte-per-lane kernels over the capture buffer
+    (zmls_dev_stream_probe; the copy overwrites the second half, so this runs after every check): a read-only sweep and
+    a copy of the first half onto the second. The step reads 16 bytes for every byte it writes, so the read rate is the
+    ceiling to hold it against. Returns (read GB/s, copy GB/s counting bytes read + written, bytes swept)."""
+    n = min(d_buf.nbytes, 64 << 30) // 8192 * 8192
     if n < (64 << 20):
         return None
-    src, dst = d_buf.ptr, d_buf.ptr + (d_buf.nbytes - n) // 4096 * 4096
     lib = _lib.lib()
-    best = None
     tm = Timer(dev)
-    for rep in range(4):
-        tm.start()
-        _lib.check(lib.zmls_dev_copy(dev, dst, src, n, None))
-        tm.stop()
-        ms = tm.elapsed_ms()
-        if rep and (best is None or ms < best):
-            best = ms
-    return 2 * n / (best * 1e-3) / 1e9
+    rates = []
+    for mode in (0, 1):
+        best = None
+        for rep in range(4):
+            tm.start()
+            _lib.check(lib.zmls_dev_stream_probe(dev, d_buf.ptr, n, mode, None))
+            tm.stop()
+            ms = tm.elapsed_ms()
+            if rep and (best is None or ms < best):
+                best = ms
+        rates.append(n / (best * 1e-3) / 1e9)
+    return rates[0], rates[1], n
 
 
-def system_check(plan, d_h, dtype_code, C, ors, ocs, seed, ch_first=0):
+def system_check(plan, d_h, dtype_code, C, ors, ocs, seed, ch_first=0, channels=None):
     """Size-independent check: the synthetic channel c is the stimulus through a known 16-tap FIR delayed by
     d_c, so the recovered response must be that FIR at lag d_c (plus averaged-down noise)."""
     worst = 0.0
-    for c in sorted({0, C // 3, C - 1}):
+    for c in (sorted({0, C // 3, C - 1}) if channels is None else channels):
         h = download_channel(plan.device, d_h.ptr, dtype_code, plan.L, ors, ocs, c).astype(np.float64)
         taps, d = plan.synth_system(ch_first + c, seed)
         # the circular autocorrelation of an MLS is 1 at lag 0 and -1/L elsewhere: a system g comes back as g(1 + 1/L) - sum(g)/L
@@ -163,10 +220,15 @@ def system_check(plan, d_h, dtype_code, C, ors, ocs, seed, ch_first=0):
     return worst
 
 
+def noise_tolerance(Ravg, L):
+    """the synthetic noise (sigma 1e-3 per sample) comes back divided by sqrt(periods * L): short sequences keep more of it"""
+    return max(1e-4, 8 * 1e-3 / np.sqrt(Ravg * L))
+
+
 def profiled_traffic(config):
-    """HBM bytes per step from the committed rocprofv3 PMC passes (profiles/, made by tools/profile_r01.sh with
-    FETCH_SIZE / WRITE_SIZE in separate runs and the gfx950 FETCH_SIZE x2 correction), if they were taken on this
-    very workload; PMC counters cannot be collected from inside a timed run, so otherwise null."""
+    """HBM bytes per step from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE / WRITE_SIZE in separate runs
+    and the gfx950 FETCH_SIZE x2 correction), if they were taken on this very workload; PMC counters cannot be collected
+    from inside a timed run, so otherwise null. The latest round's summary wins."""
     best = None
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         if not name.endswith("_summary.json"):
@@ -178,9 +240,206 @@ def profiled_traffic(config):
                     d["bench_line_of_the_traced_run"]["dtype"] == config["dtype"]:
                 t = sum(k["hbm_traffic_bytes_per_launch"] for k in d["kernels"])
                 best = (t, "profiles/" + name)
-        except (KeyError, ValueError, OSError):
+        except (KeyError, ValueError, OSError, TypeError):
             continue
     return best
+
+
+def per_kernel(pass_ms, Ravg, L, es, C):
+    """the bytes each pass kernel has to move by design (pass 1 reads the capture and writes the intermediate, later
+    passes read and write one batch each; a single-pass plan reads the capture and writes the responses) over its own
+    HIP-event time: how close each kernel is to what this part streams"""
+    out = []
+    for i, ms in enumerate(pass_ms):
+        by = ((Ravg + 1) if i == 0 else 2) * L * es * C
+        out.append({"kernel": "pass %d" % (i + 1), "ms": float(ms), "bytes_by_design": int(by),
+                    "GBps": by / (ms * 1e-3) / 1e9 if ms > 0 else None})
+    return out
+
+
+def timed_passes(plan, d_x, code, n_rows, C, rs, cs, d_h, ors, ocs, reps):
+    pass_ms = np.zeros(plan.info()["passes"])
+    for _ in range(reps):
+        pass_ms += np.array(plan.impulse_device_timed(d_x.ptr, code, n_rows, C, rs, cs, d_h.ptr, ors, ocs))
+    pass_ms /= reps
+    return pass_ms[:max(1, int(np.max(np.nonzero(pass_ms)[0], initial=0)) + 1)]   # N=21/22: the tall tile runs fewer passes
+
+
+# --------------------------------------------------------------------------------------------- the other BASELINE configs
+EXTRA_CONFIGS = [
+    # key, BASELINE.json config, order, channels, averaged periods, dtype, steps, channels checked against the oracle, of which as shipped
+    ("config1", "1: MLS order N=16, 1 channel, single period (ex_mls.py-style)", 16, 1, 1, "f64", 50, 1, 1),
+    ("config2", "2: MLS N=18, 64-channel batch, fp64 (LDS-resident FWHT)", 18, 64, 1, "f64", 50, 3, 3),
+    ("config5_f64", "5: MLS N=20 at 1024 channels, the fp64 side of the trade-off", 20, 1024, 1, "f64", 10, 3, 2),
+    ("config5_f32", "5: MLS N=20 at 1024 channels, fp32 mode", 20, 1024, 1, "f32", 10, 3, 0),
+    ("config4", "4: MLS N=24 (16.7M-sample sequence), multi-pass global FWHT beyond LDS, 256 channels", 24, 256, 1, "f64", 4, 2, 1),
+]
+
+
+def run_extra_config(spec, dev, cpu_seconds, keep):
+    key, title, N, C, Ravg, dtype, steps, n_check, n_shipped = spec
+    code, es = CODE[dtype], ESIZE[dtype]
+    R = Ravg + 1
+    plan = Plan(N, TAPS[N][0], dtype=dtype, device=dev)
+    L = plan.L
+    n_rows = R * L
+    plan.reserve(C, staging=(C % (16 // es) != 0))
+    nbytes = n_rows * C * es
+    placement = "plain hipMalloc"
+    if nbytes >= (1 << 30):
+        # large captures are placed by the plan's search (outside the timed region); two candidates at most for the
+        # ones that fill a quarter of the memory
+        d_x, ms = plan.alloc_capture(n_rows, C, code, tries=2 if nbytes > (48 << 30) else 0)
+        placement = "zmls_capture_alloc (gather pass %.2f ms)" % ms
+    else:
+        d_x = DeviceBuffer(nbytes, dev)
+    d_h = DeviceBuffer(L * C * es, dev)
+    plan.synth_device(d_x.ptr, code, R, C, C, 1, seed=SEED, sigma=1e-3)
+
+    def step():
+        plan.impulse_device(d_x.ptr, code, n_rows, C, C, 1, d_h.ptr, C, 1)
+    for _ in range(2):
+        step()
+    sync(dev)
+    tm = Timer(dev)
+    t0 = time.perf_counter()
+    tm.start()
+    for _ in range(steps):
+        step()
+    tm.stop()
+    sync(dev)
+    wall_ms = (time.perf_counter() - t0) / steps * 1e3
+    ms = tm.elapsed_ms() / steps
+    pass_ms = timed_passes(plan, d_x, code, n_rows, C, C, 1, d_h, C, 1, 2)
+    alg = (Ravg + 1) * L * es * C
+    out = {
+        "baseline_config": title,
+        "workload": "MLS N=%d, %d channel%s x %d averaged period%s, %s, (R*L, C) frame-major, one GPU" % (N, C, "s" * (C > 1), Ravg, "s" * (Ravg > 1), dtype),
+        "order": N, "channels": C, "averaged_periods": Ravg, "dtype": dtype, "steps": steps,
+        "ms_per_step": ms, "wall_ms_per_step": wall_ms, "value": C * Ravg * L / (ms * 1e-3) / 1e9, "unit": "Gsamples/s",
+        "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_step": alg,
+                     "pass_ms": [float(v) for v in pass_ms], "per_kernel": per_kernel(pass_ms, Ravg, L, es, C)},
+        "capture_placement": placement,
+    }
+    chans = sorted({0, C // 2, C - 1, C // 3})[:n_check] if C > 1 else [0]
+    out["system_check_max_abs_err"] = system_check(plan, d_h, code, C, C, 1, SEED, 0, channels=chans)
+    if cpu_seconds > 0:
+        worst, t_shipped, n_timed = oracle_parity(plan, d_x, d_h, n_rows, C, C, 1, C, 1, code, chans, timed_as_shipped=n_shipped,
+                                                  budget_s=2 * cpu_seconds)
+        out["parity_max_rel_err_vs_oracle"] = worst
+        out["parity_channels_checked"] = len(chans)
+        if n_timed:
+            out["cpu_baseline"] = {"value": n_timed * Ravg * L / t_shipped / 1e9, "unit": "Gsamples/s", "cores": 1, "kind": "port",
+                                   "sample": "%d channel%s of this workload in %.1f s; oracle/mls_oracle.py as the reference ships it "
+                                             "(per-bit Python LFSR regenerated every call + scipy fftconvolve)" % (n_timed, "s" * (n_timed > 1), t_shipped)}
+        else:
+            out["cpu_baseline"] = None
+    else:
+        out["parity_max_rel_err_vs_oracle"] = None
+        out["cpu_baseline"] = None
+    if key == "config1":
+        # the reference's own call, numpy in and numpy out through zmls_impulse_host (upload, kernels, download)
+        x = np.ascontiguousarray(d_x.download((n_rows, 1), np.float64))
+        plan.impulse_host(x)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            plan.impulse_host(x)
+        out["host_api_ms_per_call"] = (time.perf_counter() - t0) / 20 * 1e3
+    if key == "config5_f64":
+        keep["f64_responses"] = {c: download_channel(dev, d_h.ptr, code, L, C, 1, c).astype(np.float64) for c in sorted({0, C // 3, (3 * C) // 4, C - 1})}
+        keep["f64_ms"] = ms
+    if key == "config5_f32" and "f64_responses" in keep:
+        ref = keep["f64_responses"]
+        out["fp32_vs_fp64_rel_err"] = max(float(np.max(np.abs(download_channel(dev, d_h.ptr, code, L, C, 1, c).astype(np.float64) - h)) /
+                                                np.max(np.abs(h))) for c, h in ref.items())
+        out["fp32_speedup_over_fp64"] = keep["f64_ms"] / ms
+        out["cpu_baseline_note"] = "the reference has no float32 mode: see config5_f64"
+    d_x.free()
+    d_h.free()
+    plan.close()
+    return out
+
+
+# --------------------------------------------------------------------------------------------- the RCCL leg
+def period_leg(args, world, rank, dev, dist, plan, dtype_code, es, C, R, result):
+    """The same batch with the periods, not the channels, spread over the ranks (second mode): rank r
+    holds periods r, r+world, ... of ALL world*C channels, adds them up, the partial sums are reduce-scattered with RCCL
+    (zmls_impulse_period_sharded_device), and rank r transforms channel block r. Fills `result` in place."""
+    import torch
+    L = plan.L
+    Ct = world * C
+    mine, skip, total = multi.period_shard(R, world, rank)
+    n_rows = len(mine) * L
+    chunk = min(args.chunk_channels, C)
+    state = {}
+
+    def agreed(what, fn):
+        """run fn on every rank; all ranks learn whether it worked everywhere (a rank that went on alone would hang the rest)"""
+        ok, err = torch.ones(1, dtype=torch.int32), ""
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001  (RCCL refuses e.g. two ranks on one device)
+            ok[0], err = 0, "%s: %s" % (type(e).__name__, e)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            result["error"] = "%s failed over %d ranks: %s" % (what, world, err or "on another rank")
+            for k in ("d_x", "d_h"):
+                if k in state:
+                    state[k].free()
+            if "comm" in state:
+                state["comm"].close()
+            return False
+        return True
+
+    def make_comm():
+        blob = multi.torch_exchange(dist, rank, multi.make_unique_id)
+        with quiet_stdout():
+            state["comm"] = multi.Comm(blob, rank, world, dev)
+
+    def make_buffers():
+        state["d_x"] = DeviceBuffer(max(n_rows, 1) * Ct * es, dev)
+        state["d_h"] = DeviceBuffer(L * C * es, dev)
+        state["ps"] = multi.PeriodSharded(plan, state["comm"], chunk)
+        if mine:
+            plan.synth_device(state["d_x"].ptr, dtype_code, len(mine), Ct, Ct, 1, seed=SEED, sigma=1e-3)
+        sync(dev)
+
+    if not agreed("ncclCommInitRank", make_comm) or not agreed("staging for the exchange", make_buffers):
+        return
+    comm, d_x, d_h, ps = state["comm"], state["d_x"], state["d_h"], state["ps"]
+    result["rccl_ranks"] = comm.info()["world"]
+
+    def step():
+        ps.impulse_device(d_x.ptr, dtype_code, n_rows, skip, total, Ct, Ct, 1, d_h.ptr, C, 1)
+    step()
+    sync(dev)
+    dist.barrier()
+    steps = max(1, args.period_leg_steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync(dev)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item()) / steps * 1e3
+    err_sys = torch.tensor([system_check(plan, d_h, dtype_code, C, C, 1, SEED, rank * C)], dtype=torch.float64)
+    dist.all_reduce(err_sys, op=dist.ReduceOp.MAX)
+    sent = (world - 1) * C * L * es                     # bytes of partial sums that leave each GPU per step
+    result.update({
+        "ms_per_step": ms, "steps": steps, "chunk_channels": comm.info()["chunk_channels"],
+        "value": Ct * total * L / (ms * 1e-3) / 1e9, "unit": "Gsamples/s",
+        "bytes_exchanged_per_gpu_per_step": sent, "GBps_exchanged_per_gpu": sent / (ms * 1e-3) / 1e9,
+        "periods_held_by_rank0": len(multi.period_shard(R, world, 0)[0]),
+        "system_check_max_abs_err": float(err_sys.item()),
+        "workload": "the same %d channels x %d averaged periods, periods striped over %d GPUs; every rank adds up its periods, "
+                    "ncclReduceScatter(sum) of the partial sums in chunks of %d channels, rank r transforms channel block r"
+                    % (Ct, total, world, comm.info()["chunk_channels"]),
+    })
+    d_x.free()
+    d_h.free()
+    comm.close()
 
 
 def main():
@@ -199,17 +458,9 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # gloo reports its connections on stdout (C++ side); stdout carries the one JSON line
-        sys.stdout.flush()
-        keep = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with quiet_stdout():
             dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(keep, 1)
-            os.close(keep)
 
     N, C, Ravg = args.order, args.channels, args.periods
     R = Ravg + 1
@@ -218,8 +469,7 @@ def main():
         print("no GPU visible: libzmls has no CPU path", file=sys.stderr)
         sys.exit(1)
     dev = local_rank % n_dev          # fewer GPUs than ranks only happens when rehearsing the launch on a small box
-    dtype_code = _lib.ZMLS_F64 if args.dtype == "f64" else _lib.ZMLS_F32
-    es = 8 if args.dtype == "f64" else 4
+    dtype_code, es = CODE[args.dtype], ESIZE[args.dtype]
     t0 = time.perf_counter()
     plan = Plan(N, TAPS[N][0], dtype=args.dtype, device=dev)
     plan_build_s = time.perf_counter() - t0
@@ -230,20 +480,23 @@ def main():
     else:
         rs, cs, ors, ocs = 1, n_rows, 1, L
     d_h = DeviceBuffer(L * C * es, dev)
-    placement_probe_ms = None
+    placement = None
     if args.tile >= 0:
         plan.force_tile(args.tile)
+    comm = None
     if args.mode == "channel":
         seed, ch_first = SEED + 1000 * rank, 0
         plan.reserve(args.reserve_channels or C, staging=(args.layout == "capture"))
+        d_x = None
         if args.layout == "frame" and not args.plain_alloc:
             # placement of the capture in physical memory is chosen by probing (zmls_capture_alloc): outside the timed region
             try:
-                d_x, placement_probe_ms = plan.alloc_capture(n_rows, C, dtype_code)
-            except _lib.ZmlsError as e:      # e.g. not enough free memory for a second candidate: a plain buffer still measures
+                d_x, st = plan.alloc_capture(n_rows, C, dtype_code, stats=True)
+                if st["candidates_tried"]:
+                    placement = st
+            except _lib.ZmlsError as e:      # a plain buffer still measures
                 print("capture placement search failed (%s); plain allocation" % e, file=sys.stderr)
-                d_x = DeviceBuffer(n_rows * C * es, dev)
-        else:
+        if d_x is None:
             d_x = DeviceBuffer(n_rows * C * es, dev)
         plan.synth_device(d_x.ptr, dtype_code, R, C, rs, cs, seed=seed, sigma=1e-3)
 
@@ -262,15 +515,8 @@ def main():
             blob = multi.torch_exchange(dist, rank, multi.make_unique_id)
         else:
             blob = multi.make_unique_id()
-        # RCCL prints a version banner on stdout when a communicator is made; stdout carries the one JSON line
-        sys.stdout.flush()
-        keep = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with quiet_stdout():
             comm = multi.Comm(blob, rank, world, dev)
-        finally:
-            os.dup2(keep, 1)
-            os.close(keep)
         ps = multi.PeriodSharded(plan, comm, min(args.chunk_channels, C))
         if mine:
             plan.synth_device(d_x.ptr, dtype_code, len(mine), Ct, Ct, 1, seed=seed, sigma=1e-3)
@@ -305,18 +551,14 @@ def main():
 
     # ---- kernel-level timing on the launch stream (HIP events around every pass kernel)
     pass_ms = np.zeros(plan.info()["passes"])
-    reps = max(3, min(args.steps, 10))
     if args.mode == "channel":
-        for _ in range(reps):
-            pass_ms += np.array(plan.impulse_device_timed(d_x.ptr, dtype_code, n_rows, C, rs, cs, d_h.ptr, ors, ocs))
-        pass_ms /= reps
-        pass_ms = pass_ms[:max(1, int(np.max(np.nonzero(pass_ms)[0], initial=0)) + 1)]   # N=21/22: the tall tile runs fewer passes
+        pass_ms = timed_passes(plan, d_x, dtype_code, n_rows, C, rs, cs, d_h, ors, ocs, max(3, min(args.steps, 10)))
 
     alg_bytes = (Ravg + 1) * L * es * C                    # (R_avg+1)*L*sizeof(T) per channel
     achieved = alg_bytes / (pipeline_ms * 1e-3) / 1e9
     ms_per_step = elapsed / args.steps * 1e3
     out = {
-        "metric": "MLS IR deconvolution Gsamples/s + % HBM roofline, N=20, 1/2/4/8 MI355X",
+        "metric": "MLS IR deconvolution Gsamples/s + %% HBM roofline, N=%d, 1/2/4/8 MI355X" % N,
         "value": world * C * Ravg * L * args.steps / elapsed / 1e9,
         "unit": "Gsamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -340,28 +582,19 @@ def main():
             "kernel": "fwht_pass_kernel x%d (one launch sequence = one step)" % len(pass_ms),
             "alg_bytes_per_step": alg_bytes, "kernel_ms_per_step": pipeline_ms,
             "pass_ms": [float(v) for v in pass_ms],
-            "frac_of_measured_copy_rate": achieved / 6290.0,
-            # the bytes each pass kernel has to move by design (pass 1 reads the capture and writes the intermediate,
-            # later passes read and write one batch each) over its own HIP-event time: how close each kernel is to
-            # the ~6.2 TB/s this part streams; the headline `achieved` above charges the whole step to the
-            # algorithmic bytes only
-            "per_kernel": [
-                {"kernel": "pass %d" % (i + 1), "ms": float(ms),
-                 "bytes_by_design": int(((Ravg + 1) if i == 0 else 2) * L * es * C),
-                 "GBps": (((Ravg + 1) if i == 0 else 2) * L * es * C) / (ms * 1e-3) / 1e9 if ms > 0 else None}
-                for i, ms in enumerate(pass_ms)],
+            "per_kernel": per_kernel(pass_ms, Ravg, L, es, C),
         },
         "plan_build_s": plan_build_s,
-        "capture_placement_probe_ms": placement_probe_ms,
+        # what the placement search of the capture bought: gather-pass ms of the first candidate (= one plain hipMalloc
+        # in this process) against the buffer the steps above ran on
+        "capture_placement": placement,
     }
     out["system_check_max_abs_err"] = system_check(plan, d_h, dtype_code, C, ors, ocs, seed, ch_first)
-    # the synthetic noise (sigma 1e-3 per sample) comes back divided by sqrt(periods * L): short sequences keep more of it
-    check_tol = max(1e-4, 8 * 1e-3 / np.sqrt(Ravg * L))
-    if not args.no_check and out["system_check_max_abs_err"] > check_tol:
+    if not args.no_check and out["system_check_max_abs_err"] > noise_tolerance(Ravg, L):
         print("SYSTEM CHECK FAILURE on rank %d: %.3e" % (rank, out["system_check_max_abs_err"]), file=sys.stderr)
         sys.exit(3)
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.mode == "channel":
-        cpu, worst, _ = cpu_baseline_and_check(args, plan, d_x, d_h, n_rows, C, rs, cs, ors, ocs, dtype_code)
+        cpu, worst = cpu_baseline_and_check(args, plan, d_x, d_h, n_rows, C, rs, cs, ors, ocs, dtype_code)
         out["cpu_baseline"] = cpu
         out["parity_max_rel_err_vs_oracle"] = worst
         par = cpu_all_cores(N, plan.taps, R, min(8.0, args.cpu_seconds))
@@ -369,25 +602,74 @@ def main():
             cpu["all_cores"] = {"value": par[0] / 1e9, "unit": "Gsamples/s", "cores": par[1],
                                 "sample": "%d oracle calls on capture-shaped noise (N=%d, %d averaged periods) by %d independent "
                                           "processes in %.1f s" % (par[2], N, Ravg, par[1], par[3])}
-        tol = 1e-12 if args.dtype == "f64" else 1e-5
-        if not args.no_check and worst > tol:
-            print("PARITY FAILURE: %.3e > %.1e" % (worst, tol), file=sys.stderr)
+        if not args.no_check and worst > TOL[args.dtype]:
+            print("PARITY FAILURE: %.3e > %.1e" % (worst, TOL[args.dtype]), file=sys.stderr)
             sys.exit(2)
     else:
         out["cpu_baseline"] = None
-    cal = copy_calibration(dev, d_x)
+    cal = stream_calibration(dev, d_x)
     if cal:
-        out["roofline"]["copy_calibration_GBps"] = cal          # hipMemcpy device-to-device in this run, read + written bytes
-        out["roofline"]["frac_of_same_run_copy_rate"] = out["roofline"]["achieved"] / cal
+        roof = out["roofline"]
+        roof["stream_read_GBps"], roof["stream_copy_GBps"] = cal[0], cal[1]
+        roof["stream_calibration"] = ("hand-written 16 B/lane kernels over %.1f GB of the capture buffer in this run: read-only sweep, "
+                                      "and copy of one half onto the other (bytes read + written)" % (cal[2] / 1e9))
+        roof["frac_of_same_run_read_rate"] = achieved / cal[0]
     prof = profiled_traffic(dict(out["config"], dtype=args.dtype))
     if prof:
         out["roofline"]["traffic"] = prof[0]
         out["roofline"]["traffic_source"] = "%s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per step, all pass kernels)" % prof[1]
+
+    # ---- everything below runs on memory the headline has given back
+    d_x.free()
+    d_h.free()
+    if comm is not None:
+        comm.close()
+
+    if world > 1 and args.mode == "channel" and args.period_leg == "auto":
+        # the RCCL leg must never cost the line above: it runs beside a deadline, and a rank that finds it stuck
+        # reports that and leaves
+        result = {}
+        th = threading.Thread(target=lambda: _guard(period_leg, result, args, world, rank, dev, dist, plan, dtype_code, es, C, R, result), daemon=True)
+        th.start()
+        th.join(args.period_leg_timeout)
+        if th.is_alive():
+            result = {"error": "the period-sharded leg did not finish within %.0f s" % args.period_leg_timeout}
+            out["period_mode"] = result
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        out["period_mode"] = result
+    plan.close()
+
+    run_configs = args.configs == "all" or (args.configs == "auto" and (N, C, Ravg, args.dtype, args.layout, args.mode) == (20, 512, 16, "f64", "frame", "channel"))
+    if rank == 0 and world == 1 and run_configs:
+        keep, extra = {}, []
+        for spec in EXTRA_CONFIGS:
+            try:
+                extra.append(run_extra_config(spec, dev, args.cpu_seconds, keep))
+            except Exception as e:  # noqa: BLE001  (the headline must survive a failure here; the entry says what happened)
+                extra.append({"baseline_config": spec[1], "error": "%s: %s" % (type(e).__name__, e)})
+        out["configs"] = extra
+        bad = [c for c in extra if "error" in c or (c.get("parity_max_rel_err_vs_oracle") or 0) > TOL[c["dtype"]]
+               or c["system_check_max_abs_err"] > noise_tolerance(c["averaged_periods"], (1 << c["order"]) - 1)]
+        if bad and not args.no_check:
+            print("CONFIG FAILURE: %s" % json.dumps(bad)[:2000], file=sys.stderr)
+            sys.exit(4)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:  # noqa: BLE001  (a rank that left early must not turn a printed line into a failure)
+            print("rank %d: %s at the closing barrier" % (rank, type(e).__name__), file=sys.stderr)
+
+
+def _guard(fn, result, *a):
+    try:
+        fn(*a)
+    except Exception as e:  # noqa: BLE001
+        result["error"] = "%s: %s" % (type(e).__name__, e)
 
 
 if __name__ == "__main__":

@@ -17,6 +17,10 @@
  *     workspace). Launch entry points (`*_device`) never allocate, free or
  *     synchronise; they enqueue on the caller's HIP stream.
  *   - one plan is not thread-safe; different plans are independent.
+ *
+ * Everything here replaces a piece of the reference (cited per entry point) or is needed to use those pieces on a
+ * GPU. Hooks for the tests, the benchmark and tuning (synthetic captures, device memory for ctypes callers, per-pass
+ * timing, plan internals) are declared in zmls_testing.h.
  */
 #ifndef ZMLS_H
 #define ZMLS_H
@@ -71,12 +75,6 @@ int zmls_plan_reserve_staging(zmls_plan *p, int64_t n_ch);
  * info[13]=passes of the tall-tile schedule (2 for N = 21, 22: wide aligned batches then take 11-bit passes, two
  * instead of info[4]'s three; 0 elsewhere) info[14..15]=its bits per pass */
 int zmls_plan_info(const zmls_plan *p, int64_t info[16]);
-/* Tile configuration used by the impulse entry points: -1 = chosen per call (default), 0 = small tile
- * (64 KiB, 64-byte row segments, any layout), 1 = big tile (256 KiB, 256-byte row segments), 2 = mid tile
- * (128 KiB, 128-byte row segments), 3 = tall tile (256 KiB, 2^11 rows of 128 bytes; orders 21 and 22 only);
- * 1, 2 and 3 need contiguous, 16-byte aligned channels. Tuning bits: +256
- * switches the XCD-aware block mapping off, +1024 lays the workspace out row-major. */
-int zmls_plan_force_tile(zmls_plan *p, int cfg);
 /* Raw PCM captures: replaces Audio.convert_to_float (zignal/audio.py:565-589, samples / 2^(sourcebits-1)) on the
  * way from sndcard.PA.play_rec / a wav file (zignal/sndcard.py:296-318, audio.py:1108-1123) to get_impulse.
  * With k = sourcebits-1 set, the impulse entry points take the int16/int32 frames as they are (ZMLS_I16/ZMLS_I32,
@@ -122,13 +120,6 @@ int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_r
 int zmls_impulse_device_static(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch,
                                int64_t row_stride, int64_t ch_stride,
                                void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
-/* profiling variant (bench.py): same launches with a HIP event either side of every pass kernel on
- * `hip_stream`; synchronises and returns the milliseconds of pass i in pass_ms[i] (summed over channel
- * chunks). Creates and destroys its events: not for timed or captured regions. */
-int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch,
-                              int64_t row_stride, int64_t ch_stride,
-                              void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream,
-                              float pass_ms[4]);
 /* host buffers: uploads, runs, downloads, synchronous. h element type = plan dtype. */
 int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch,
                       int64_t row_stride, int64_t ch_stride,
@@ -138,8 +129,14 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
  * buffer lies in physical memory changes the speed of the gather pass by 5-25 % (measured; api.hip), so up to
  * `tries` candidate allocations (0 = default 4) are rated with the plan's own gather pass and the fastest is kept;
  * *probe_ms (may be null) receives its gather-pass time. Captures under 1 GiB are simply allocated. Free with
- * zmls_dev_free. Allocates, launches and synchronises: plan-time only. No counterpart in the reference. */
+ * zmls_capture_free (it is plain device memory: hipFree works as well). Allocates, launches and synchronises:
+ * plan-time only. No counterpart in the reference.
+ * stats (may be null): [0] candidate allocations rated, [1] gather-pass ms of the first candidate (= what one plain
+ * hipMalloc would have given in this process), [2] ms of the buffer returned, [3] ms the pass should take on a good
+ * placement (the model the search stops at), [4] search rounds. */
 int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch, int tries, void **d_x, float *probe_ms);
+int zmls_capture_alloc_stats(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch, int tries, void **d_x, float stats[8]);
+int zmls_capture_free(zmls_plan *p, void *d_x);
 
 /* ---- the averaging step alone: replaces trim_and_avgerage (mls.py:258-313) when it is called
  * on its own. out: (L, n_ch) C-contiguous HOST buffer, float32 when in_dtype is ZMLS_F32 (numpy
@@ -230,54 +227,6 @@ int zmls_spectrum_device(zmls_spectrum *s, const double *d_h, int64_t row_stride
                          const double *d_window, int normalise, double *d_mag, void *hip_stream);
 /* host buffers: h (n_samples, n_ch) C-contiguous, window n_samples or null, mag (bins, n_ch); synchronous */
 int zmls_spectrum_host(zmls_spectrum *s, const double *h, const double *window, int normalise, double *mag);
-
-/* ---- synthetic captures for benchmarking/tests (no reference counterpart; the
- * shape follows examples/ex_mls.py:16-28: stimulus through a short filter with a
- * delay, plus noise). Channel c: 16-tap decaying FIR g_c, delay d_c =
- * (c*9973) mod L, sigma*noise per sample, `repeats` periods, steady state.
- * Writes element type `dtype` with the given strides. */
-int zmls_synth_device(zmls_plan *p, void *d_x, int dtype, int64_t repeats, int64_t n_ch, int64_t ch_first,
-                      int64_t row_stride, int64_t ch_stride, uint64_t seed, double sigma, void *hip_stream);
-/* the FIR the synthetic channel c uses (16 doubles) and its delay */
-int zmls_synth_system(const zmls_plan *p, int64_t channel, uint64_t seed, double *taps16, int64_t *delay);
-
-/* ---- device memory and streams for ctypes callers that have no HIP binding of
- * their own (bench.py, tests). Thin wrappers over hipMalloc, hipFree, hipMemcpy and the
- * hipStream / hipEvent calls, on the given device. */
-int zmls_dev_alloc(int device, void **d_ptr, size_t bytes);
-int zmls_dev_free(int device, void *d_ptr);
-int zmls_dev_upload(int device, void *d_dst, const void *src, size_t bytes);
-int zmls_dev_download(int device, void *dst, const void *d_src, size_t bytes);
-int zmls_dev_memset(int device, void *d_ptr, int value, size_t bytes);
-int zmls_dev_copy(int device, void *d_dst, const void *d_src, size_t bytes, void *hip_stream);   /* device to device, asynchronous */
-int zmls_dev_sync(int device);
-int zmls_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
-int zmls_stream_create(int device, void **stream);
-int zmls_stream_destroy(int device, void *stream);
-int zmls_stream_sync(int device, void *stream);
-int zmls_event_create(int device, void **event);
-int zmls_event_destroy(int device, void *event);
-int zmls_event_record(int device, void *event, void *stream);
-int zmls_event_elapsed_ms(int device, void *start, void *stop, float *ms); /* synchronises on `stop` */
-/* strided 2-D gather of one channel into a contiguous device/host buffer (tests: pull column c of a big capture) */
-int zmls_dev_download_channel(int device, void *dst, const void *d_src, int dtype, int64_t n_rows,
-                              int64_t row_stride, int64_t ch_stride, int64_t channel);
-
-/* ---- plan internals for tests (tables in natural order, host buffers of 2^N uint32):
- * which=0: gather table   Q[d] = j with Ps[j] = d   (Q[0] = 0xFFFFFFFF)
- * which=1: scatter table  M[d] = m with Pl[m] = d   (M[0] = 0xFFFFFFFF)
- * Ps / Pl as defined in SURVEY.md §A.2. */
-int zmls_plan_export_table(zmls_plan *p, int which, uint32_t *out);
-
-/* ---- host-only helpers (no GPU needed; used by the CPU test tier) */
-/* how a 2^N-point transform is split into LDS-resident passes: bits[i] for i < returned count */
-int zmls_host_pass_split(int N, int bits[4]);
-/* state of the N-bit Fibonacci register after `steps` steps from the reference's initial state, computed
- * with the same GF(2) jump-ahead matrices the device kernels use; bit i = sequence bit (steps + i). */
-int zmls_host_lfsr_state(int N, const int32_t *taps, int ntaps, uint64_t steps, uint32_t *state);
-/* enumerate the tile geometry of one pass and verify every element is covered exactly once per round and
- * every LDS slot / workspace row is in range; returns 0 if consistent. */
-int zmls_host_geometry_selfcheck(int K, int tile_cfg, int first_pass);
 
 #ifdef __cplusplus
 }

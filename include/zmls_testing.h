@@ -1,0 +1,98 @@
+/* zmls_testing.h — hooks of libzmls.so for its tests, its benchmark and tuning.
+ *
+ * None of these has a counterpart in the reference (zignal v0.6.0) and none is needed to use the library: a
+ * program that binds libzmls in place of zignal/measure/mls.py needs include/zmls.h only. They exist because the
+ * Python tests and bench.py reach the GPU through ctypes alone (no HIP binding of their own), and because the
+ * benchmark has to make its captures on the device (BASELINE config 3 is 73 GB per GPU).
+ */
+#ifndef ZMLS_TESTING_H
+#define ZMLS_TESTING_H
+
+#include "zmls.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- tuning */
+/* Tile configuration used by the impulse entry points: -1 = chosen per call (default), 0 = small tile
+ * (64 KiB, 64-byte row segments, any layout), 1 = big tile (256 KiB, 256-byte row segments), 2 = mid tile
+ * (128 KiB, 128-byte row segments), 3 = tall tile (256 KiB, 2^11 rows of 128 bytes; orders 21 and 22 only);
+ * 1, 2 and 3 need contiguous, 16-byte aligned channels. Tuning bits: +256
+ * switches the XCD-aware block mapping off, +1024 lays the workspace out row-major. */
+int zmls_plan_force_tile(zmls_plan *p, int cfg);
+
+/* ---- per-pass timing */
+/* profiling variant (bench.py): same launches with a HIP event either side of every pass kernel on
+ * `hip_stream`; synchronises and returns the milliseconds of pass i in pass_ms[i] (summed over channel
+ * chunks). Creates and destroys its events: not for timed or captured regions. */
+int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch,
+                              int64_t row_stride, int64_t ch_stride,
+                              void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream,
+                              float pass_ms[4]);
+
+/* ---- synthetic captures for benchmarking/tests (no reference counterpart; the
+ * shape follows examples/ex_mls.py:16-28: stimulus through a short filter with a
+ * delay, plus noise). Channel c: 16-tap decaying FIR g_c, delay d_c =
+ * (c*9973) mod L, sigma*noise per sample, `repeats` periods, steady state.
+ * Writes element type `dtype` with the given strides. */
+int zmls_synth_device(zmls_plan *p, void *d_x, int dtype, int64_t repeats, int64_t n_ch, int64_t ch_first,
+                      int64_t row_stride, int64_t ch_stride, uint64_t seed, double sigma, void *hip_stream);
+/* the FIR the synthetic channel c uses (16 doubles) and its delay */
+int zmls_synth_system(const zmls_plan *p, int64_t channel, uint64_t seed, double *taps16, int64_t *delay);
+
+/* ---- device memory and streams for ctypes callers that have no HIP binding of
+ * their own (bench.py, tests). Thin wrappers over hipMalloc, hipFree, hipMemcpy and the
+ * hipStream / hipEvent calls, on the given device. */
+int zmls_dev_alloc(int device, void **d_ptr, size_t bytes);
+int zmls_dev_free(int device, void *d_ptr);
+int zmls_dev_upload(int device, void *d_dst, const void *src, size_t bytes);
+int zmls_dev_download(int device, void *dst, const void *d_src, size_t bytes);
+int zmls_dev_memset(int device, void *d_ptr, int value, size_t bytes);
+int zmls_dev_copy(int device, void *d_dst, const void *d_src, size_t bytes, void *hip_stream);   /* device to device, asynchronous */
+int zmls_dev_sync(int device);
+int zmls_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
+int zmls_stream_create(int device, void **stream);
+int zmls_stream_destroy(int device, void *stream);
+int zmls_stream_sync(int device, void *stream);
+int zmls_event_create(int device, void **event);
+int zmls_event_destroy(int device, void *event);
+int zmls_event_record(int device, void *event, void *stream);
+int zmls_event_elapsed_ms(int device, void *start, void *stop, float *ms); /* synchronises on `stop` */
+/* strided 2-D gather of one channel into a contiguous device/host buffer (tests: pull column c of a big capture) */
+int zmls_dev_download_channel(int device, void *dst, const void *d_src, int dtype, int64_t n_rows,
+                              int64_t row_stride, int64_t ch_stride, int64_t channel);
+
+/* ---- plan internals for tests (tables in natural order, host buffers of 2^N uint32):
+ * which=0: gather table   Q[d] = j with Ps[j] = d   (Q[0] = 0xFFFFFFFF)
+ * which=1: scatter table  M[d] = m with Pl[m] = d   (M[0] = 0xFFFFFFFF)
+ * Ps / Pl as defined in SURVEY.md §A.2. */
+int zmls_plan_export_table(zmls_plan *p, int which, uint32_t *out);
+
+/* ---- host-only helpers (no GPU needed; used by the CPU test tier) */
+/* how a 2^N-point transform is split into LDS-resident passes: bits[i] for i < returned count */
+int zmls_host_pass_split(int N, int bits[4]);
+/* state of the N-bit Fibonacci register after `steps` steps from the reference's initial state, computed
+ * with the same GF(2) jump-ahead matrices the device kernels use; bit i = sequence bit (steps + i). */
+int zmls_host_lfsr_state(int N, const int32_t *taps, int ntaps, uint64_t steps, uint32_t *state);
+/* enumerate the tile geometry of one pass and verify every element is covered exactly once per round and
+ * every LDS slot / workspace row is in range; returns 0 if consistent. */
+int zmls_host_geometry_selfcheck(int K, int tile_cfg, int first_pass);
+
+/* the capture placement search of zmls_capture_alloc (zmls_host.cpp::placement_search) on a made-up machine: the
+ * i-th buffer ever allocated is gathered in ms_of_alloc[i % n_ms] milliseconds and at most max_live buffers fit in
+ * memory at once. out: [0] index of the allocation kept (-1 none) [1] candidates rated [2] first candidate's
+ * microseconds [3] the kept buffer's microseconds [4] rounds [5] 1 if an allocation failed [6] buffers still
+ * allocated at the end [7] most buffers allocated at once. */
+int zmls_host_placement_sim(const float *ms_of_alloc, int n_ms, int max_live, int tries, float model_ms, int64_t out[8]);
+
+/* ---- what this GPU streams, measured in the same run as the benchmark (bench.py's roofline calibration): hand-written
+ * 16-byte-per-lane kernels over `bytes` bytes at d_buf (a multiple of 4096; the buffer's contents are destroyed by mode 1).
+ * mode 0: read only (every lane adds up what it loads; nothing is written). mode 1: copy of the first half onto the
+ * second half. Enqueues one kernel on hip_stream. */
+int zmls_dev_stream_probe(int device, void *d_buf, size_t bytes, int mode, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZMLS_TESTING_H */

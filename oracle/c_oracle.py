@@ -23,6 +23,7 @@ def lib():
         i32p = ctypes.POINTER(ctypes.c_int32)
         _lib.mls_oracle_bits.argtypes = [ctypes.c_int, i32p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
         _lib.mls_oracle_bits_packed.argtypes = _lib.mls_oracle_bits.argtypes
+        _lib.mls_oracle_bits_packed_word.argtypes = _lib.mls_oracle_bits.argtypes
         _lib.mls_oracle_sequence.argtypes = [ctypes.c_int, i32p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
         _lib.mls_oracle_average.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_void_p]
@@ -48,6 +49,16 @@ def bits_packed(N, taps, nbits=None):
     out = np.empty((nbits + 7) // 8, dtype=np.uint8)
     t, n = _taps(taps)
     if lib().mls_oracle_bits_packed(N, t, n, out.ctypes.data, nbits):
+        raise ValueError("bad LFSR arguments")
+    return out
+
+
+def bits_packed_word(N, taps, nbits=None):
+    """bits_packed from the register held in one machine word (orders 31, 32 in reasonable time)"""
+    nbits = (1 << N) - 1 if nbits is None else nbits
+    out = np.empty((nbits + 7) // 8, dtype=np.uint8)
+    t, n = _taps(taps)
+    if lib().mls_oracle_bits_packed_word(N, t, n, out.ctypes.data, nbits):
         raise ValueError("bad LFSR arguments")
     return out
 

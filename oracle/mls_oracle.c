@@ -72,6 +72,28 @@ int mls_oracle_bits_packed(int N, const int32_t *taps, int ntaps, uint8_t *out, 
     return 0;
 }
 
+/* The same register held in one 64-bit word (bit k = cells[k]): the XOR over cells[N - tap] is the parity of
+ * (register & mask), dropping cells[0] is a shift, the new bit goes in at position N-1 (mls.py:101-108 again, a
+ * few nanoseconds per bit instead of a memmove). For the two orders whose period is too long for the byte-cell
+ * loop above in a test (N = 31, 32: 2 and 4 Gbit); tests/test_oracle_golden.py holds it to the same reference
+ * digests and to mls_oracle_bits_packed. */
+int mls_oracle_bits_packed_word(int N, const int32_t *taps, int ntaps, uint8_t *out, int64_t nbits)
+{
+    if (N < 1 || N > 64 || ntaps < 1 || ntaps > 64) return -1;
+    uint64_t mask = 0, reg = 1ull << (N - 1);
+    for (int i = 0; i < ntaps; i++) {
+        if (taps[i] < 1 || taps[i] > N) return -1;
+        mask ^= 1ull << (N - taps[i]);          /* a tap listed twice cancels, as it does in the XOR loop */
+    }
+    memset(out, 0, (size_t)((nbits + 7) / 8));
+    for (int64_t i = 0; i < nbits; i++) {
+        const uint64_t bit = (uint64_t)__builtin_parityll(reg & mask);
+        reg = (reg >> 1) | (bit << (N - 1));
+        if (bit) out[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
+    return 0;
+}
+
 /* (repeats*L) samples: bit 0 -> +1.0, bit 1 -> -1.0 (mls.py:150), one fresh
  * period tiled (mls.py:162-164). */
 int mls_oracle_sequence(int N, const int32_t *taps, int ntaps, double *out, int64_t repeats)

@@ -107,6 +107,22 @@ def dump_seq_kats(quick):
     write_json("seq_kat.json", {"kats": out, "generator_chunk": cont})
 
 
+def dump_seq_prefix():
+    """Orders beyond the full-period KATs (one N=32 period is ~100 minutes of the reference's per-bit loop): the first
+    2^20 bits of the generator, straight from generator_chunk, for the first and last tap set of N = 25..32."""
+    nbits = 1 << 20
+    out = []
+    t0 = time.time()
+    for N in range(25, 33):
+        for taps in (TAPS[N][0], TAPS[N][-1]):
+            bits = next(_MLS_base(N, tuple(taps)).generator_chunk(nbits))[:, 0].astype(np.uint8)
+            packed = np.packbits(bits, bitorder="little")
+            out.append({"N": N, "taps": list(taps), "nbits": nbits, "ones": int(bits.sum()), "sha256": inputs.digest(packed),
+                        "first64": "".join(str(int(b)) for b in bits[:64])})
+        print("seq prefix N=%d %.0fs" % (N, time.time() - t0), flush=True)
+    write_json("seq_prefix.json", {"prefixes": out})
+
+
 # --------------------------------------------------------------------------- IR goldens
 def ref_impulse(N, taps, x):
     m = _MLS_base(N, tuple(taps))
@@ -291,7 +307,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     steps = {"taps": dump_taps, "errors": dump_errors, "api": dump_api, "fft": dump_fft,
-             "seq": lambda: dump_seq_kats(a.quick), "ir": lambda: dump_ir(a.quick)}
+             "seq": lambda: dump_seq_kats(a.quick), "prefix": dump_seq_prefix, "ir": lambda: dump_ir(a.quick)}
     for name, fn in steps.items():
         if a.only and name not in a.only.split(","):
             continue

@@ -50,6 +50,8 @@ def test_bench_prints_one_json_line_with_the_agreed_fields(extra):
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and roof["achieved"] > 0
     assert d["system_check_max_abs_err"] < (1e-4 if "f32" not in extra else 1e-3)
+    assert "capture_placement" in d and "configs" not in d          # small captures are not searched; extra configs ride on the default workload only
+    assert "frac_of_measured_copy_rate" not in roof
     if "period" in extra:
         assert d["cpu_baseline"] is None
     else:
@@ -72,3 +74,34 @@ def test_two_ranks_print_one_json_line_too():
     assert REQUIRED <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     L = (1 << 14) - 1
     assert abs(d["value"] - 2 * 32 * 3 * L / (d["ms_per_step"] * 1e-3) / 1e9) <= 1e-6 * d["value"]
+    # the RCCL leg rides on every N > 1 run. Two ranks on two GPUs: a two-rank communicator moved the partial sums.
+    # Two ranks sharing the one GPU of a test box: RCCL refuses the communicator, every rank learns of it, and the
+    # line says so instead of a number.
+    pm = d["period_mode"]
+    if "error" in pm:
+        assert _lib.device_count() < 2, pm["error"]
+        assert "ncclCommInitRank" in pm["error"]
+    else:
+        assert pm["rccl_ranks"] == 2 and pm["ms_per_step"] > 0 and pm["GBps_exchanged_per_gpu"] > 0
+        assert pm["system_check_max_abs_err"] < 1e-4
+
+
+@pytest.mark.gpu
+def test_extra_config_entry_carries_roofline_parity_and_cpu_baseline():
+    """bench.py's `configs` entries (BASELINE configs 1, 2, 4, 5 at full size in the driver's run), on a small stand-in."""
+    sys.path.insert(0, ROOT)
+    import bench
+    keep = {}
+    e64 = bench.run_extra_config(("config5_f64", "stand-in", 13, 32, 1, "f64", 3, 2, 1), 0, 1.0, keep)
+    e32 = bench.run_extra_config(("config5_f32", "stand-in", 13, 32, 1, "f32", 3, 2, 0), 0, 1.0, keep)
+    e1 = bench.run_extra_config(("config1", "stand-in", 12, 1, 1, "f64", 3, 1, 1), 0, 1.0, keep)
+    for e, tol in ((e64, 1e-12), (e32, 1e-5), (e1, 1e-12)):
+        assert {"workload", "dtype", "ms_per_step", "value", "roofline", "parity_max_rel_err_vs_oracle", "cpu_baseline",
+                "system_check_max_abs_err"} <= set(e)
+        r = e["roofline"]
+        assert r["alg_bytes_per_step"] == 2 * ((1 << e["order"]) - 1) * e["channels"] * (8 if e["dtype"] == "f64" else 4)
+        assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12 and e["ms_per_step"] > 0
+        assert e["parity_max_rel_err_vs_oracle"] <= tol
+    assert e64["cpu_baseline"]["kind"] == "port" and e64["cpu_baseline"]["value"] > 0
+    assert e32["cpu_baseline"] is None and 0 < e32["fp32_vs_fp64_rel_err"] <= 1e-5 and e32["fp32_speedup_over_fp64"] > 0
+    assert e1["host_api_ms_per_call"] > 0 and e1["cpu_baseline"]["cores"] == 1

@@ -46,22 +46,33 @@ def channel(p, d_buf, n_rows, C, c):
     return download_channel(0, d_buf.ptr, p.dtype_code, n_rows, C, 1, c).astype(np.float64)
 
 
-def check_channels(p, d_x, d_h, C, R, chans, tol, oracle_chans, sigma):
+def one_per_slab(C, slab=16):
+    """one channel of every 16-channel block (the widest tile's slab in f64; two per slab in f32), at a position that
+    walks through the slab, so that a defect confined to one slab - or to one lane group of every slab - shows"""
+    return [s * slab + (5 * s + 3) % slab for s in range(C // slab)]
+
+
+def check_channels(p, d_x, d_h, C, R, chans, tol, oracle_chans, sigma, capture_chans=None):
+    """known-system check on every channel of `chans` (one download of the response each); the sum identity, which
+    needs the capture too, on `capture_chans` (default: all of them); the oracle on `oracle_chans`"""
     ref = c_oracle.sequence(p.N, p.taps)
-    for c in chans:
+    capture_chans = set(chans if capture_chans is None else capture_chans) | set(oracle_chans)
+    for c in sorted(set(chans) | capture_chans):
         h = channel(p, d_h, p.L, C, c)
-        assert np.all(np.isfinite(h))
+        assert np.all(np.isfinite(h)), c
+        if sigma == 0.0:
+            assert np.max(np.abs(h - expected_noise_free(p, c))) <= tol, c
+        else:
+            # noise averages down by sqrt(periods * L): far below 1e-4 of the unit peak at these sizes
+            assert np.max(np.abs(h - expected_noise_free(p, c))) <= 1e-4, c
+        if c not in capture_chans:
+            continue
         x = channel(p, d_x, R * p.L, C, c)
         avg = x[p.L:].reshape(R - 1, p.L).mean(axis=0)
         # sum of the response = -(1/L) sum of the averaged capture (autocorrelation sums to 1 per lag: L - (L-1))
-        assert abs(h.sum() + avg.sum() / p.L) <= tol * max(1.0, np.abs(avg).sum() / p.L) * (10 if tol < 1e-9 else 1000)
-        if sigma == 0.0:
-            assert np.max(np.abs(h - expected_noise_free(p, c))) <= tol
-        else:
-            # noise averages down by sqrt(periods * L): far below 1e-4 of the unit peak at these sizes
-            assert np.max(np.abs(h - expected_noise_free(p, c))) <= 1e-4
+        assert abs(h.sum() + avg.sum() / p.L) <= tol * max(1.0, np.abs(avg).sum() / p.L) * (10 if tol < 1e-9 else 1000), c
         if c in oracle_chans:
-            assert rel_err(h, oracle_ir(p.N, p.taps, x.reshape(-1, 1), ref)) <= tol
+            assert rel_err(h, oracle_ir(p.N, p.taps, x.reshape(-1, 1), ref)) <= tol, c
 
 
 def test_config2_n18_64_channels_f64():
@@ -75,7 +86,8 @@ def test_config2_n18_64_channels_f64():
 def test_config3_share_n20_512_channels_16_periods_f64():
     N, C, R = 20, 512, 17
     p, d_x, d_h = run_batch(N, C, R, "f64", 1e-3)
-    check_channels(p, d_x, d_h, C, R, (0, 15, 16, 255, 511), 1e-12, {0, 511}, 1e-3)
+    # 32 slabs of 16 channels: one channel of each, plus the corners
+    check_channels(p, d_x, d_h, C, R, one_per_slab(C) + [0, 15, 16, 511], 1e-12, {0, 511}, 1e-3, capture_chans=(0, 15, 16, 255, 511))
     d_x.free()
     d_h.free()
     p.close()
@@ -85,7 +97,7 @@ def test_config4_n24_256_channels_three_passes_f64():
     N, C, R = 24, 256, 2
     p, d_x, d_h = run_batch(N, C, R, "f64", 0.0)
     assert p.info()["passes"] == 3
-    check_channels(p, d_x, d_h, C, R, (0, 100, 255), 1e-12, {100}, 0.0)
+    check_channels(p, d_x, d_h, C, R, one_per_slab(C) + [0, 255], 1e-12, {100}, 0.0, capture_chans=(0, 100, 255))
     d_x.free()
     d_h.free()
     p.close()
@@ -96,7 +108,7 @@ def test_config5_n20_1024_channels_f32_against_f64():
     p64, d_x64, d_h64 = run_batch(N, C, R, "f64", 1e-3)
     chans = (0, 333, 1023)
     h64 = {c: channel(p64, d_h64, p64.L, C, c) for c in chans}
-    check_channels(p64, d_x64, d_h64, C, R, chans, 1e-12, {333}, 1e-3)
+    check_channels(p64, d_x64, d_h64, C, R, one_per_slab(C) + list(chans), 1e-12, {333}, 1e-3, capture_chans=chans)
     d_x64.free()
     d_h64.free()
     p64.close()
@@ -104,7 +116,7 @@ def test_config5_n20_1024_channels_f32_against_f64():
     for c in chans:
         # same synthetic capture rounded to float32, float32 arithmetic: the accuracy side of the trade-off
         assert rel_err(channel(p32, d_h32, p32.L, C, c), h64[c]) <= 1e-5
-    check_channels(p32, d_x32, d_h32, C, R, chans, 1e-5, {1023}, 1e-3)
+    check_channels(p32, d_x32, d_h32, C, R, one_per_slab(C) + list(chans), 1e-5, {1023}, 1e-3, capture_chans=chans)
     d_x32.free()
     d_h32.free()
     p32.close()

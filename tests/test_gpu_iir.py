@@ -43,7 +43,10 @@ def test_every_order_against_lfilter_single_channel(order):
 
 
 @pytest.mark.parametrize("shape,dtype", [((70000, 3), np.float64), ((20011, 16), np.float64), ((9000, 37), np.float32),
-                                         ((50000, 5), np.int16), ((4097, 1), np.int32)])
+                                         ((50000, 5), np.int16), ((4097, 1), np.int32),
+                                         # the chunks' start states come from the second-level scan: 586 chunks = 3 groups of
+                                         # 256 frame-major, 37 chunks = 1 group time-contiguous; then 18 and 2 groups
+                                         ((300007, 6), np.float64), ((2300000, 2), np.float32)])
 def test_frames_by_channels_and_dtypes(shape, dtype):
     rng = np.random.default_rng(shape[0] + shape[1])
     B, A = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=48000).get_coefficients()

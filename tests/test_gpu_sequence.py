@@ -41,6 +41,73 @@ def test_sequence_beyond_reference_reach_matches_c_oracle(N):
     assert np.array_equal(plan(N, taps).bits_packed(), c_oracle.bits_packed(N, taps))
 
 
+PREFIXES = load_json("seq_prefix.json")["prefixes"]
+
+
+def _ones(packed, nbits):
+    full, total = nbits // 8, 0
+    for i in range(0, full, 1 << 26):
+        total += int(np.bitwise_count(packed[i:min(full, i + (1 << 26))]).sum(dtype=np.int64))
+    if nbits % 8:
+        total += bin(int(packed[full]) & ((1 << (nbits % 8)) - 1)).count("1")
+    return total
+
+
+def _bit(packed, i):
+    return (int(packed[i >> 3]) >> (i & 7)) & 1
+
+
+@pytest.mark.parametrize("kat", [k for k in PREFIXES if k["N"] <= 30], ids=_kat_id)
+def test_sequence_prefix_of_large_orders_matches_reference_digest(kat):
+    """N = 25..30: the first 2^20 bits against the digest of what the reference's own generator_chunk emits"""
+    from zignal_amd.device import Plan
+    p = Plan(kat["N"], kat["taps"], device=0)
+    packed = p.bits_packed(kat["nbits"])
+    p.close()
+    assert inputs.digest(packed) == kat["sha256"]
+
+
+@pytest.mark.parametrize("N", [31, 32])
+def test_orders_31_and_32_generate_the_sequence_and_decline_the_transform(N):
+    """The end of zignal's tap table (mlstaps.py): the generator covers it - the whole 2^N - 1 bit period equals the C
+    oracle's (word register; its first 2^20 bits are pinned to the reference's in tests/test_oracle_golden.py) and the
+    reference's own first 2^20 bits - while impulse responses end at N = 30 (the workspace of one channel slab alone
+    would be 137 / 275 GB) and say so."""
+    import ctypes
+    from zignal_amd import _lib
+    from zignal_amd.device import DeviceBuffer, Plan
+    for taps in (TAPS[N][0], TAPS[N][-1]):
+        p = Plan(N, taps, device=0)
+        L = p.L
+        kat = [k for k in PREFIXES if k["N"] == N and tuple(k["taps"]) == tuple(taps)][0]
+        assert inputs.digest(p.bits_packed(kat["nbits"])) == kat["sha256"]
+        if taps == TAPS[N][0]:
+            got = p.bits_packed(L + 32)               # one period and on across its end (mls.py:117-128)
+            want = c_oracle.bits_packed_word(N, taps, L + 32)
+            assert got.size == want.size and np.array_equal(got, want)
+            # a maximum-length sequence has 2^(N-1) ones per period and closes on itself
+            assert _ones(got, L) == 1 << (N - 1)
+            assert [_bit(got, L + i) for i in range(32)] == [_bit(got, i) for i in range(32)]
+            del want
+        assert p.info()["passes"] == 0
+        d = DeviceBuffer(1 << 20)
+        rc = _lib.lib().zmls_impulse_device(p._h, d.ptr, 0, 2 * L, 2, 2, 1, d.ptr, 2, 1, None)
+        assert rc == _lib.E_UNSUPPORTED and "up to order 30" in _lib.last_error()
+        assert _lib.lib().zmls_plan_reserve(p._h, 2) == _lib.E_UNSUPPORTED
+        # the +1/-1 stimulus on the device follows the bits (first 2^16 samples of a float32 copy)
+        if taps == TAPS[N][0]:
+            d_s = DeviceBuffer(L * 4)
+            _lib.check(_lib.lib().zmls_sequence_device(p._h, d_s.ptr, _lib.ZMLS_F32, 1, 1, None))
+            s = d_s.download((1 << 16,), np.float32)
+            bits = np.unpackbits(got[:1 << 13], bitorder="little")
+            assert np.array_equal(s, 1.0 - 2.0 * bits.astype(np.float32))
+            d_s.free()
+        d.free()
+        p.close()
+    with pytest.raises(_lib.ZmlsError):
+        Plan(33, (33, 20), device=0)
+
+
 def test_sequence_samples_and_generators():
     g = KATS["generator_chunk"]
     m = _MLS_base(g["N"], tuple(g["taps"]), device=0)
@@ -106,7 +173,7 @@ def test_every_tap_set_of_the_reference_table():
     n_sets = 0
     for N in sorted(TAPS):
         if N > 30:
-            continue                                  # tables are uint32 with a sentinel: orders 31, 32 are not built
+            continue                                  # orders 31, 32: test_orders_31_and_32_generate_the_sequence_...
         for taps in (TAPS[N] if N <= 26 else (TAPS[N][0], TAPS[N][-1])):
             p = Plan(N, taps, device=0)
             if N <= 22:

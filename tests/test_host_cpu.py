@@ -26,10 +26,16 @@ def lib():
     return _lib.lib()
 
 
-def header_functions():
-    txt = open(os.path.join(ROOT, "include", "zmls.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(zmls_[a-z0-9_]+)\s*\(", txt)))
+HEADERS = ("zmls.h", "zmls_testing.h")      # the product ABI, and the hooks of the tests / the benchmark
+
+
+def header_functions(name=None):
+    names = set()
+    for h in ([name] if name else HEADERS):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(zmls_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -40,6 +46,51 @@ def test_library_exports_every_declared_symbol(lib):
     # and the ctypes table covers them all (plus zmls_last_error, bound separately)
     assert set(names) - {"zmls_last_error"} == set(_lib.SIGNATURES)
     assert lib.zmls_version() >= 100
+
+
+def test_product_header_holds_no_test_hooks():
+    """A maintainer binding the library reads zmls.h: every entry point there takes over a piece of the reference (or is
+    needed to run those pieces on a GPU); memory / stream / event wrappers, synthetic input, timing and plan internals
+    live in zmls_testing.h."""
+    product, hooks = set(header_functions("zmls.h")), set(header_functions("zmls_testing.h"))
+    assert not product & hooks
+    assert not [n for n in product if n.startswith(("zmls_dev_", "zmls_stream_", "zmls_event_", "zmls_host_", "zmls_synth_"))]
+    assert {"zmls_plan_export_table", "zmls_plan_force_tile", "zmls_impulse_device_timed"} <= hooks
+    assert {"zmls_plan_create", "zmls_sequence_bits", "zmls_impulse_device", "zmls_impulse_host", "zmls_impulse_device_static"} <= product
+
+
+def _placement(ms, max_live, tries=4, model=12.5):
+    arr = (ctypes.c_float * len(ms))(*ms)
+    out = (ctypes.c_int64 * 8)()
+    rc = _lib.lib().zmls_host_placement_sim(arr, len(ms), max_live, tries, model, out)
+    return rc, dict(zip(("kept", "rated", "first_us", "final_us", "rounds", "alloc_failed", "live_at_end", "peak_live"), list(out)))
+
+
+def test_capture_placement_search_host_logic(lib):
+    """zmls_capture_alloc's search (zmls_host.cpp::placement_search) on a simulated machine."""
+    # the first candidate already sits on the floor the model predicts: taken at once, rated again, nothing else allocated
+    rc, r = _placement([12.6, 13.5, 14.5], max_live=4)
+    assert rc == 0 and r["kept"] == 0 and r["rated"] == 1 and r["live_at_end"] == 1 and r["peak_live"] == 1 and not r["alloc_failed"]
+    # a slow first candidate: the search goes on until one reaches the floor, and gives the rest back
+    rc, r = _placement([14.5, 13.5, 12.6, 12.6], max_live=4)
+    assert rc == 0 and r["kept"] == 2 and r["first_us"] == 14500 and r["final_us"] == 12600 and r["live_at_end"] == 1
+    assert r["peak_live"] <= 3                                     # the best and at most two rejected candidates
+    # a plateau above a floor that is in reach needs a third vote, then another round is tried with the winner kept
+    rc, r = _placement([13.5], max_live=4)
+    assert rc == 0 and r["final_us"] == 13500 and r["rounds"] == 3 and r["live_at_end"] == 1 and r["peak_live"] <= 4
+    # shapes the model does not fit (everything far above it): two candidates that agree are enough, one round
+    rc, r = _placement([20.0, 20.1], max_live=4)
+    assert rc == 0 and r["rated"] == 2 and r["rounds"] == 1 and r["final_us"] == 20000
+    # FALLBACK, memory holds one capture only (a capture above half of the free memory): the first allocation is the
+    # answer, rated once, and the search says that it had no choice
+    rc, r = _placement([14.5, 12.6], max_live=1)
+    assert rc == 0 and r["kept"] == 0 and r["rated"] == 1 and r["alloc_failed"] == 1 and r["final_us"] == 14500 and r["live_at_end"] == 1
+    # memory holds two: the better of two, never more than two alive
+    rc, r = _placement([14.5, 13.5, 12.6], max_live=2)
+    assert rc == 0 and r["kept"] in (1, 2) and r["peak_live"] == 2 and r["alloc_failed"] == 1 and r["live_at_end"] == 1
+    # memory holds none: an error, nothing leaked
+    rc, r = _placement([12.6], max_live=0)
+    assert rc == _lib.E_HIP and r["kept"] == -1 and r["live_at_end"] == 0
 
 
 def test_pass_split(lib):

@@ -55,6 +55,31 @@ def test_c_oracle_sequence_kat(kat):
     assert "".join(map(str, bits[:64])) == kat["first64"]
 
 
+PREFIXES = load_json("seq_prefix.json")["prefixes"]
+
+
+@pytest.mark.parametrize("kat", PREFIXES, ids=lambda k: "N%d-%s" % (k["N"], "_".join(map(str, k["taps"]))))
+def test_c_oracle_sequence_prefix_of_the_largest_orders(kat):
+    """N = 25..32 (the end of the reference's tap table): the first 2^20 bits as the reference's generator_chunk emits
+    them, from both C restatements (byte cells, and the register in one word that the N = 31, 32 GPU tests lean on)."""
+    N, taps, nbits = kat["N"], kat["taps"], kat["nbits"]
+    for fn in (c_oracle.bits_packed, c_oracle.bits_packed_word):
+        packed = fn(N, taps, nbits)
+        assert inputs.digest(packed) == kat["sha256"], fn.__name__
+    bits = np.unpackbits(packed, bitorder="little")[:nbits]
+    assert int(bits.sum()) == kat["ones"] and "".join(map(str, bits[:64])) == kat["first64"]
+
+
+@pytest.mark.parametrize("kat", [k for k in KATS["kats"] if k["N"] <= 20],
+                         ids=lambda k: "N%d-%s" % (k["N"], "_".join(map(str, k["taps"]))))
+def test_word_register_oracle_sequence_kat(kat):
+    packed = c_oracle.bits_packed_word(kat["N"], kat["taps"])
+    assert inputs.digest(packed) == kat["sha256"]
+    # ... and on across the period boundary, like the cell version
+    n = (1 << kat["N"]) + 77
+    assert np.array_equal(c_oracle.bits_packed_word(kat["N"], kat["taps"], n), c_oracle.bits_packed(kat["N"], kat["taps"], n))
+
+
 def test_c_oracle_matches_python_oracle_samples():
     for N, taps in ((5, (5, 4, 3, 2)), (9, (9, 5)), (12, (12, 11, 10, 4))):
         a = mls_oracle.full_sequence(N, taps, 3)

@@ -29,7 +29,7 @@ for r in csv.DictReader(open(stats)):
         kernels[r["Name"]] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                               "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6}
 pmc = collections.defaultdict(dict)
-for name in ("fetch", "write", "sq", "tcc", "grbm"):
+for name in ("fetch", "write", "sq", "tcc", "grbm", "wrreq", "rdreq", "sq2", "tcc2", "lat"):
     f = one(src + name + "/vm/*_counter_collection.csv")
     if not f:
         continue

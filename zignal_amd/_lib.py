@@ -44,6 +44,8 @@ SIGNATURES = {
                                   ctypes.POINTER(ctypes.c_float)],
     "zmls_impulse_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64],
     "zmls_capture_alloc": [c_vp, c_int, c_i64, c_i64, c_int, _vpp, ctypes.POINTER(ctypes.c_float)],
+    "zmls_capture_alloc_stats": [c_vp, c_int, c_i64, c_i64, c_int, _vpp, ctypes.POINTER(ctypes.c_float)],
+    "zmls_capture_free": [c_vp, c_vp],
     "zmls_average_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp],
     "zmls_comm_unique_id": [c_vp],
     "zmls_comm_create": [_vpp, c_vp, c_int, c_int, c_int],
@@ -88,6 +90,8 @@ SIGNATURES = {
     "zmls_host_pass_split": [c_int, ctypes.POINTER(c_int)],
     "zmls_host_lfsr_state": [c_int, _i32p, c_int, c_u64, ctypes.POINTER(ctypes.c_uint32)],
     "zmls_host_geometry_selfcheck": [c_int, c_int, c_int],
+    "zmls_host_placement_sim": [ctypes.POINTER(ctypes.c_float), c_int, c_int, c_int, ctypes.c_float, ctypes.POINTER(c_i64)],
+    "zmls_dev_stream_probe": [c_int, c_vp, c_sz, c_int, c_vp],
 }
 
 _lib = None

@@ -131,18 +131,23 @@ class Audio(object):
             sp.close()
         return frq, mag
 
-    def plot_fft(self, plotname=None, window='hamming', normalise=True, **kwargs):
-        """Magnitude response plot (audio.py:649-676): the spectrum comes from `fft` (GPU); drawing it is
-        matplotlib's job and outside this library's scope beyond this minimal figure."""
+    def plot_fft(self, plotname=None, window='hann', normalise=True, **kwargs):
+        """Magnitude response plot with the reference's defaults (audio.py:649-676: hann window, one labelled line per
+        channel, nothing below 1 Hz, floor `ymin` = -160 dB). The spectrum comes from `fft` (GPU); the drawing is matplotlib's."""
         import matplotlib.pyplot as plt
+        ymin = kwargs.get('ymin', -160)
         freq, mag = self.fft(window=window, normalise=normalise)
-        plt.figure()
-        plt.semilogx(freq[1:], mag[1:])
+        fig = plt.figure()
+        for ch in range(self.ch):
+            plt.semilogx(freq, mag[:, ch], label='ch%2i' % (ch + 1))
+        plt.xlim(left=1)
+        plt.ylim(bottom=ymin)
         plt.xlabel('Frequency [Hz]')
         plt.ylabel('Magnitude [dB]')
+        plt.legend(loc='best')
         plt.grid(True)
         if plotname is None:
             plt.show()
         else:
             plt.savefig(plotname)
-            plt.close()
+            plt.close(fig)

@@ -2,6 +2,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <vector>
 #include "zmls_internal.h"
 
@@ -21,15 +22,34 @@ size_t dtype_size(int dt)
 
 int use_device(int device)
 {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        set_error("no HIP device available (%s); libzmls has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
-        return ZMLS_E_NODEVICE;
+    // the device count does not change while the process lives: one runtime call per launch less
+    static std::atomic<int> n_cached{0};
+    int n = n_cached.load(std::memory_order_relaxed);
+    if (n <= 0) {
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) {
+            set_error("no HIP device available (%s); libzmls has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+            return ZMLS_E_NODEVICE;
+        }
+        n_cached.store(n, std::memory_order_relaxed);
     }
     if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return ZMLS_E_NODEVICE; }
-    ZHIP(hipSetDevice(device));
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device) ZHIP(hipSetDevice(device));
     return ZMLS_OK;
+}
+
+// Entry points make their object's device current for the duration of the call and put the caller's device back on
+// the way out: a host program that holds another device current (torch, a second plan) does not find it changed.
+DeviceScope::DeviceScope(int device)
+{
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    rc = use_device(device);
+    if (rc || prev == device) prev = -1;
+}
+DeviceScope::~DeviceScope()
+{
+    if (prev >= 0) (void)hipSetDevice(prev);
 }
 
 // Large device allocations are made twice. Measured on MI355X / ROCm 7.2: the first hipMalloc of a
@@ -99,6 +119,16 @@ int build_plan(zmls_plan *p)
     // period boundary; rounded up to whole threads of the generator
     p->n_words = ((n + 64 + 1023) / 1024) * 32;
     ZHIP(hipMalloc((void **)&p->d_bits, p->n_words * 4));
+    if (p->N > kMaxTransformOrder) {
+        // orders 31 and 32: the bit sequence only (zmls_internal.h::kMaxTransformOrder). Without the tables, whose
+        // completeness is the proof elsewhere, the period is checked with powers of the state matrix on the host.
+        if (!period_is_maximal(p->N, jt)) { set_error("taps do not generate a maximum-length sequence of order %d", p->N); return ZMLS_E_UNSUPPORTED; }
+        int rc = launch_lfsr_tables(p->N, p->G, p->s0, p->d_jt, p->d_bits, p->n_words, nullptr, nullptr, 0);
+        if (rc) return rc;
+        p->npass = 0;
+        ZHIP(hipDeviceSynchronize());
+        return ZMLS_OK;
+    }
     ZHIP(hipMalloc((void **)&p->d_gather, n * 4));
     ZHIP(hipMalloc((void **)&p->d_scatter_nat, n * 4));
     ZHIP(hipMemsetAsync(p->d_gather, 0xFF, n * 4, 0));
@@ -160,8 +190,7 @@ int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int
     uint32_t G, s0;
     int rc = validate_taps(N, taps, ntaps, &G, &s0);
     if (rc) return rc;
-    rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
     {
         // set-up for zmls_impulse_device_static: this device's address of the static workspace, so that the
         // launch path itself never has to ask the runtime for it
@@ -190,7 +219,8 @@ int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int
 int zmls_plan_destroy(zmls_plan *p)
 {
     if (!p) return ZMLS_OK;
-    if (hipSetDevice(p->device) == hipSuccess) free_plan_buffers(p);
+    DeviceScope on_device(p->device);
+    if (!on_device.rc) free_plan_buffers(p);
     free(p);
     return ZMLS_OK;
 }
@@ -198,9 +228,10 @@ int zmls_plan_destroy(zmls_plan *p)
 int zmls_plan_reserve(zmls_plan *p, int64_t n_ch)
 {
     if (!p || n_ch < 1) { set_error("bad reserve arguments"); return ZMLS_E_ARG; }
+    if (int rc = sequence_only(p)) return rc;
     if (p->npass == 1) return ZMLS_OK;   // single-pass plans keep everything in LDS
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
     // the widest slab among the tile configurations a call with n_ch channels can end up on: the small tile always, a
     // wide one only when the batch fills at least one of its slabs or it is forced (a 256-byte slab of a 2^30-point
     // transform alone is 275 GB: single-channel plans of the largest orders must not be charged for it)
@@ -223,9 +254,10 @@ int zmls_plan_reserve(zmls_plan *p, int64_t n_ch)
 int zmls_plan_reserve_staging(zmls_plan *p, int64_t n_ch)
 {
     if (!p || n_ch < 1) { set_error("bad reserve arguments"); return ZMLS_E_ARG; }
+    if (int rc = sequence_only(p)) return rc;
     if (p->npass == 1) return ZMLS_OK;   // single-pass plans read and write any layout directly
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
     const size_t ts = dtype_size(p->dtype);
     const int64_t E = (int64_t)(kVecBytes / ts);
     const size_t need = (size_t)p->L * (size_t)((n_ch + E - 1) / E * E) * ts;
@@ -245,9 +277,13 @@ int zmls_plan_force_tile(zmls_plan *p, int cfg)
 {
     if (!p || cfg < -1 || (cfg >= 0 && (cfg & 0xFF) >= CFG_COUNT)) { set_error("tile configuration must be -1 (auto), 0 (small), 1 (big), 2 (mid) or 3 (tall)"); return ZMLS_E_ARG; }
     if (cfg >= 0 && (cfg & 0xFF) == CFG_TALL && !p->tall_npass) { set_error("the tall tile exists for orders 21 and 22 only"); return ZMLS_E_UNSUPPORTED; }
+    if (cfg >= 0 && ((cfg & 0xFF) == CFG_BIG || (cfg & 0xFF) == CFG_TALL) && p->npass == 1) {
+        set_error("orders up to 10 run as one pass in the small or the mid tile; the big and tall tiles do not apply");
+        return ZMLS_E_UNSUPPORTED;
+    }
     if (cfg >= 0 && (cfg & 0xFF) == CFG_BIG) {
-        int rc = use_device(p->device);
-        if (!rc) rc = build_scatter_perm(p, CFG_BIG);
+        ZDEVICE(p->device);
+        int rc = build_scatter_perm(p, CFG_BIG);
         if (rc) return rc;
         ZHIP(hipDeviceSynchronize());                     // callers may launch on streams that do not wait for the null stream
     }
@@ -279,8 +315,8 @@ int zmls_plan_info(const zmls_plan *p, int64_t info[16])
 int zmls_sequence_bits(zmls_plan *p, uint8_t *out, int64_t nbits)
 {
     if (!p || !out || nbits < 0 || (uint64_t)nbits > (1ull << p->N) + 32) { set_error("bad sequence_bits arguments"); return ZMLS_E_ARG; }
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
     const size_t nbytes = (size_t)((nbits + 7) / 8);
     if (!nbytes) return ZMLS_OK;
     ZHIP(hipMemcpy(out, p->d_bits, nbytes, hipMemcpyDeviceToHost));
@@ -291,16 +327,16 @@ int zmls_sequence_bits(zmls_plan *p, uint8_t *out, int64_t nbits)
 int zmls_sequence_device(zmls_plan *p, void *d_out, int dtype, int64_t repeats, int64_t stride, void *stream)
 {
     if (!p || !d_out || repeats < 1 || stride < 1) { set_error("bad sequence_device arguments"); return ZMLS_E_ARG; }
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
     return launch_sequence_expand(p->d_bits, p->L, d_out, dtype, repeats, stride, (hipStream_t)stream);
 }
 
 int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
 {
     if (!p || !out || repeats < 1) { set_error("bad sequence_f64 arguments"); return ZMLS_E_ARG; }
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
     double *d = nullptr;
     ZHIP(hipMalloc((void **)&d, (size_t)p->L * 8));
     rc = launch_sequence_expand(p->d_bits, p->L, d, ZMLS_F64, 1, 1, 0);
@@ -317,6 +353,15 @@ int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
 } // extern "C"
 
 namespace zmls {
+// plans of orders 31 and 32 hold the bit sequence only
+int sequence_only(const zmls_plan *p)
+{
+    if (p->npass > 0) return ZMLS_OK;
+    set_error("order %d: the sequence is generated, impulse responses are supported up to order %d (one 64-byte-row slab of the "
+              "intermediate of a 2^%d-point transform alone is %.0f GB, beside %d GiB of tables and the capture)", p->N, kMaxTransformOrder, p->N,
+              (double)work_rows_total(p->N) * 64.0 / 1e9, (int)((2ull << p->N) * 4 >> 30));
+    return ZMLS_E_UNSUPPORTED;
+}
 // the launch sequence of the passes on buffers as they are (no layout adapters)
 // `work` / `work_bytes`: the intermediate between the passes; the plan's own workspace unless the caller brings another
 // (static_ws.hip), in which case a tile configuration whose slab does not fit gives way to the next narrower one.
@@ -329,12 +374,13 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
     const bool own_work = work == nullptr;
     if (own_work) { work = p ? p->d_work : nullptr; work_bytes = p ? p->work_bytes : 0; }
     if (!p || !d_x || (!d_h && !gather_pass_only)) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (int rc = sequence_only(p)) return rc;
     if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
     if (n_ch < 1) { set_error("need at least one channel"); return ZMLS_E_ARG; }
     if (row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("strides must be positive"); return ZMLS_E_ARG; }
     if (periods < 1 || periods > 0x7FFFFFFF || divisor < 1 || divisor > 0x7FFFFFFF) { set_error("period count out of range"); return ZMLS_E_ARG; }
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
 
     const size_t ts = dtype_size(p->dtype);
     const int E = (int)(kVecBytes / ts);
@@ -480,6 +526,7 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
                         int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms, int gather_pass_only)
 {
     if (!p || !d_x || (!d_h && !gather_pass_only)) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (int rc = sequence_only(p)) return rc;
     const size_t is = dtype_size(in_dtype), ts = dtype_size(p->dtype);
     if (!is) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
     if (n_ch < 1) { set_error("need at least one channel"); return ZMLS_E_ARG; }
@@ -497,8 +544,8 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
     if (!in_cm && !in_fm && !out_cm)
         return run_passes(p, d_x, in_dtype, periods, skip_periods, divisor, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride,
                           st, ev, pass_ms, gather_pass_only, nullptr, 0);
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
     for (int64_t c0 = 0; c0 < n_ch; c0 += cc) {
         const int64_t n = (n_ch - c0 < cc) ? n_ch - c0 : cc;
         const int64_t Cs = (n + E - 1) / E * E;
@@ -560,8 +607,7 @@ int zmls_impulse_device_timed(zmls_plan *p, const void *d_x, int in_dtype, int64
     int64_t periods = 0;
     int rc = capture_periods(p, n_rows, &periods);
     if (rc) return rc;
-    rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
     hipEvent_t ev[8];
     int made = 0;
     for (; made < 8; ++made)
@@ -604,8 +650,7 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
     int64_t periods = 0;
     int rc = capture_periods(p, n_rows, &periods);
     if (rc) return rc;
-    rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
     rc = zmls_plan_reserve(p, n_ch);
     if (rc) return rc;
     {
@@ -652,13 +697,14 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
 // Where a capture lies in physical memory decides how fast the gather pass reads it: on MI355X / ROCm 7.2 the same
 // 73 GB capture (N=20, 512 channels, 17 periods) at the same virtual address is gathered in 12.6-12.8 ms on some
 // allocations and 13.3-15.6 ms on others, stable for the lifetime of the allocation (tools/alloc_probe.py; neither
-// hipDeviceMallocContiguous nor hipMemCreate/hipMemMap placement changed that). So a capture buffer is chosen:
-// candidates are allocated one after the other, each is rated with this plan's own gather pass, the fastest is
-// kept. Rejected candidates stay allocated while the search runs, so the driver cannot hand the same memory back.
-int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch, int tries, void **d_x, float *probe_ms)
+// hipDeviceMallocContiguous nor hipMemCreate/hipMemMap placement changed that). So a capture buffer is chosen: the
+// search itself is placement_search (zmls_host.cpp); here are its three callbacks on the real device.
+int zmls_capture_alloc_stats(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch, int tries, void **d_x, float stats[8])
 {
     if (!p || !d_x) { set_error("null argument"); return ZMLS_E_ARG; }
     *d_x = nullptr;
+    if (stats) memset(stats, 0, sizeof(float) * 8);
+    if (int rc0 = sequence_only(p)) return rc0;
     const size_t is = dtype_size(in_dtype);
     if (!is) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
     int64_t periods = 0;
@@ -666,34 +712,36 @@ int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch,
     if (rc) return rc;
     if (n_ch < 1) { set_error("need at least one channel"); return ZMLS_E_ARG; }
     if (tries < 1) tries = 4;
-    rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
     const size_t bytes = (size_t)n_rows * (size_t)n_ch * is;
     // small captures, and plans that do everything in one LDS-resident pass, have nothing to choose
     const bool probe = tries > 1 && p->npass > 1 && bytes >= ((size_t)1 << 30);
     if (!probe) {
         ZHIP(hipMalloc(d_x, bytes));
-        if (probe_ms) *probe_ms = 0.f;
         return ZMLS_OK;
     }
     rc = zmls_plan_reserve(p, n_ch);
     if (rc) return rc;
-    hipEvent_t ev[2];
-    ZHIP(hipEventCreate(&ev[0]));
-    ZHIP(hipEventCreate(&ev[1]));
-    void *best = nullptr, *rejected[2] = {nullptr, nullptr};
-    float best_ms = 0.f;
-    auto reject = [&](void *q) {
-        if (rejected[0]) (void)hipFree(rejected[0]);      // at most two rejected candidates are held at a time
-        rejected[0] = rejected[1];
-        rejected[1] = q;
+    struct Ctx { zmls_plan *p; int in_dtype; int64_t periods, n_ch; size_t bytes; hipEvent_t ev[2]; } ctx = {p, in_dtype, periods, n_ch, bytes, {nullptr, nullptr}};
+    ZHIP(hipEventCreate(&ctx.ev[0]));
+    ZHIP(hipEventCreate(&ctx.ev[1]));
+    PlacementOps ops;
+    ops.ctx = &ctx;
+    ops.alloc = [](void *c) -> void * {
+        Ctx *x = (Ctx *)c;
+        void *cand = nullptr;
+        if (hipMalloc(&cand, x->bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemsetAsync(cand, 0, x->bytes, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(cand); return nullptr; }
+        return cand;
     };
+    ops.release = [](void *, void *q) { (void)hipFree(q); };
     // gather-pass time on a candidate: the first run warms up, the faster of the next two counts
-    auto rate = [&](void *cand, float *ms_out) -> int {
+    ops.rate = [](void *c, void *cand, float *ms_out) -> int {
+        Ctx *x = (Ctx *)c;
         float ms = 0.f, pass_ms[4];
         for (int rep = 0; rep < 3; ++rep) {
             pass_ms[0] = 0.f;
-            int r = impulse_device_core(p, cand, in_dtype, periods, 1, periods, n_ch, n_ch, 1, nullptr, n_ch, 1, 0, ev, pass_ms, 1);
+            int r = impulse_device_core(x->p, cand, x->in_dtype, x->periods, 1, x->periods, x->n_ch, x->n_ch, 1, nullptr, x->n_ch, 1, 0, x->ev, pass_ms, 1);
             if (r) return r;
             if (rep == 1 || (rep == 2 && pass_ms[0] < ms)) ms = pass_ms[0];
         }
@@ -702,75 +750,36 @@ int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch,
     };
     // What the gather pass of this shape takes on a good placement: the capture read at 5.85 TB/s plus the intermediate
     // written at 5.2 TB/s, the rates the pass reaches on MI355X (fits 12.5 ms at N=20 x 512 x 16 periods, 3.1 ms at
-    // N=20 x 1024 x 1, 12.5 ms at N=24 x 256 x 1). Placements come in plateaus (headline: 12.5-12.7 ms,
-    // 13.3-13.6 ms, now and then 14.5+), so two candidates that agree can both sit on the upper one: the model tells a
-    // plateau from the floor.
+    // N=20 x 1024 x 1, 12.5 ms at N=24 x 256 x 1).
     const double cells = (double)p->L * (double)n_ch;
     const double model_ms = cells * (double)periods * (double)is / 5.85e9 + cells * (double)dtype_size(p->dtype) / 5.2e9;
-    auto at_floor = [&](float ms) { return ms <= (float)(model_ms * 1.025); };
-    auto floor_in_reach = [&](float ms) { return ms <= (float)(model_ms * 1.15); };     // shapes the model fits at all
-    // A placement can also lose its speed when the candidates it was compared with are given back (seen about once
-    // in twelve searches: 12.6 ms before, 13.6 ms after, for the life of the buffer). So the winner is rated again
-    // after the others are freed; if it no longer holds its time, or sits on a plateau above a floor that is in
-    // reach, the search is repeated with it kept allocated (so that its memory is not handed out again).
-    void *keep = nullptr;
-    float keep_ms = 0.f;
-    for (int round = 0; round < 3 && !rc; ++round) {
-        float second_ms = 0.f;
-        int rated = 0;
-        best = nullptr; best_ms = 0.f;
-        for (int t = 0; t < tries; ++t) {
-            void *cand = nullptr;
-            hipError_t e = hipMalloc(&cand, bytes);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                if (!best && !keep) rc = hip_fail(e, "hipMalloc(capture)");
-                break;                                    // memory is full of candidates: settle for the best so far
-            }
-            float ms = 0.f;
-            e = hipMemsetAsync(cand, 0, bytes, 0);
-            if (e != hipSuccess) rc = hip_fail(e, "capture placement probe");
-            if (!rc) rc = rate(cand, &ms);
-            if (rc) { (void)hipFree(cand); break; }
-            ++rated;
-            if (!best || ms < best_ms) {
-                if (best) reject(best);
-                second_ms = best ? best_ms : 0.f;
-                best = cand; best_ms = ms;
-            } else {
-                if (second_ms == 0.f || ms < second_ms) second_ms = ms;
-                reject(cand);
-            }
-            if (at_floor(best_ms)) break;
-            // two candidates within 2 % of each other at the top: a plateau. Where the model says a lower one is in
-            // reach, a third candidate has to agree before it is taken for the floor
-            if (second_ms > 0.f && second_ms <= best_ms * 1.02f && (!floor_in_reach(best_ms) || rated >= 3)) break;
-        }
-        for (int i = 0; i < 2; ++i) {
-            if (rejected[i]) (void)hipFree(rejected[i]);
-            rejected[i] = nullptr;
-        }
-        if (rc) { if (best) (void)hipFree(best); best = nullptr; break; }
-        if (!best) break;                                  // nothing new could be allocated: keep what there is
-        if (keep && keep_ms <= best_ms) { (void)hipFree(best); }
-        else {
-            if (keep) (void)hipFree(keep);
-            keep = best; keep_ms = best_ms;
-        }
-        best = nullptr;
-        float again = 0.f;
-        rc = rate(keep, &again);
-        if (rc) break;
-        const bool holds = again <= keep_ms * 1.03f;
-        keep_ms = again;
-        if (holds && (at_floor(again) || !floor_in_reach(again))) break;
+    PlacementStats st;
+    rc = placement_search(ops, tries, model_ms, d_x, &st);
+    (void)hipEventDestroy(ctx.ev[0]);
+    (void)hipEventDestroy(ctx.ev[1]);
+    if (rc) return rc;
+    if (stats) {
+        stats[0] = (float)st.candidates; stats[1] = st.first_ms; stats[2] = st.final_ms; stats[3] = st.model_ms;
+        stats[4] = (float)st.rounds; stats[5] = (float)st.alloc_failed;
     }
-    best = keep; best_ms = keep_ms;
-    (void)hipEventDestroy(ev[0]);
-    (void)hipEventDestroy(ev[1]);
-    if (rc) { if (best) (void)hipFree(best); return rc; }
-    *d_x = best;
-    if (probe_ms) *probe_ms = best_ms;
+    return ZMLS_OK;
+}
+
+int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch, int tries, void **d_x, float *probe_ms)
+{
+    float stats[8];
+    const int rc = zmls_capture_alloc_stats(p, in_dtype, n_rows, n_ch, tries, d_x, stats);
+    if (probe_ms) *probe_ms = rc ? 0.f : stats[2];
+    return rc;
+}
+
+int zmls_capture_free(zmls_plan *p, void *d_x)
+{
+    if (!p) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (!d_x) return ZMLS_OK;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
+    ZHIP(hipFree(d_x));
     return ZMLS_OK;
 }
 
@@ -782,8 +791,8 @@ int zmls_average_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
     if (!is) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
     if (n_ch < 1 || row_stride < 1 || ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
     if (n_rows <= p->L || n_rows % p->L) { set_error("frame count %lld must be a multiple of L=%lld and larger than L", (long long)n_rows, (long long)p->L); return ZMLS_E_ARG; }
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
     const size_t os = (in_dtype == ZMLS_F32) ? 4 : 8;
     const size_t in_span = (size_t)((n_rows - 1) * row_stride + (n_ch - 1) * ch_stride + 1) * is;
     const size_t out_bytes = (size_t)p->L * n_ch * os;
@@ -806,8 +815,8 @@ int zmls_synth_device(zmls_plan *p, void *d_x, int dtype, int64_t repeats, int64
                       int64_t ch_stride, uint64_t seed, double sigma, void *stream)
 {
     if (!p || !d_x || repeats < 1 || n_ch < 1 || row_stride < 1 || ch_stride < 1) { set_error("bad synth arguments"); return ZMLS_E_ARG; }
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
     return launch_synth(p->d_bits, p->L, d_x, dtype, repeats, n_ch, ch_first, row_stride, ch_stride, seed, sigma, (hipStream_t)stream);
 }
 
@@ -821,8 +830,9 @@ int zmls_synth_system(const zmls_plan *p, int64_t channel, uint64_t seed, double
 int zmls_plan_export_table(zmls_plan *p, int which, uint32_t *out)
 {
     if (!p || !out || which < 0 || which > 1) { set_error("bad export arguments"); return ZMLS_E_ARG; }
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    if (int rc0 = sequence_only(p)) return rc0;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
     ZHIP(hipMemcpy(out, which == 0 ? p->d_gather : p->d_scatter_nat, ((size_t)1 << p->N) * 4, hipMemcpyDeviceToHost));
     return ZMLS_OK;
 }
@@ -830,65 +840,65 @@ int zmls_plan_export_table(zmls_plan *p, int which, uint32_t *out)
 // ---- thin HIP wrappers for ctypes callers ---------------------------------------------------
 int zmls_dev_alloc(int device, void **d_ptr, size_t bytes)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(settled_malloc(d_ptr, bytes));
     return ZMLS_OK;
 }
 int zmls_dev_free(int device, void *d_ptr)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipFree(d_ptr));
     return ZMLS_OK;
 }
 int zmls_dev_upload(int device, void *d_dst, const void *src, size_t bytes)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
     return ZMLS_OK;
 }
 int zmls_dev_download(int device, void *dst, const void *d_src, size_t bytes)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return ZMLS_OK;
 }
 int zmls_dev_memset(int device, void *d_ptr, int value, size_t bytes)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipMemset(d_ptr, value, bytes));
     return ZMLS_OK;
 }
 int zmls_dev_copy(int device, void *d_dst, const void *d_src, size_t bytes, void *stream)
 {
     if (!d_dst || !d_src) { set_error("null argument"); return ZMLS_E_ARG; }
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return ZMLS_OK;
 }
 int zmls_dev_sync(int device)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipDeviceSynchronize());
     return ZMLS_OK;
 }
 int zmls_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipMemGetInfo(free_bytes, total_bytes));
     return ZMLS_OK;
 }
 int zmls_stream_create(int device, void **stream)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     hipStream_t s;
     ZHIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *stream = (void *)s;
@@ -896,22 +906,22 @@ int zmls_stream_create(int device, void **stream)
 }
 int zmls_stream_destroy(int device, void *stream)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipStreamDestroy((hipStream_t)stream));
     return ZMLS_OK;
 }
 int zmls_stream_sync(int device, void *stream)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipStreamSynchronize((hipStream_t)stream));
     return ZMLS_OK;
 }
 int zmls_event_create(int device, void **event)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     hipEvent_t ev;
     ZHIP(hipEventCreate(&ev));
     *event = (void *)ev;
@@ -919,22 +929,22 @@ int zmls_event_create(int device, void **event)
 }
 int zmls_event_destroy(int device, void *event)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipEventDestroy((hipEvent_t)event));
     return ZMLS_OK;
 }
 int zmls_event_record(int device, void *event, void *stream)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
     return ZMLS_OK;
 }
 int zmls_event_elapsed_ms(int device, void *start, void *stop, float *ms)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     ZHIP(hipEventSynchronize((hipEvent_t)stop));
     ZHIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return ZMLS_OK;
@@ -942,8 +952,8 @@ int zmls_event_elapsed_ms(int device, void *start, void *stop, float *ms)
 int zmls_dev_download_channel(int device, void *dst, const void *d_src, int dtype, int64_t n_rows, int64_t row_stride,
                               int64_t ch_stride, int64_t channel)
 {
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     const size_t es = dtype_size(dtype);
     if (!es) { set_error("bad dtype"); return ZMLS_E_ARG; }
     void *d_tmp = nullptr;

@@ -115,8 +115,8 @@ int zmls_comm_create(zmls_comm **out, const uint8_t *id, int rank, int n_ranks, 
     if (!out || !id) { set_error("null argument"); return ZMLS_E_ARG; }
     *out = nullptr;
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) { set_error("rank %d outside 0..%d", rank, n_ranks - 1); return ZMLS_E_ARG; }
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     Rccl *R = rccl();
     if (!R) return ZMLS_E_COMM;
     zmls_comm *c = (zmls_comm *)calloc(1, sizeof(zmls_comm));
@@ -147,7 +147,8 @@ int zmls_comm_create(zmls_comm **out, const uint8_t *id, int rank, int n_ranks, 
 int zmls_comm_destroy(zmls_comm *c)
 {
     if (!c) return ZMLS_OK;
-    if (hipSetDevice(c->device) == hipSuccess) {
+    DeviceScope on_device(c->device);
+    if (!on_device.rc) {
         (void)hipDeviceSynchronize();
         free_staging(c);
         for (int i = 0; i < 2; ++i) {
@@ -175,8 +176,8 @@ int zmls_comm_reserve(zmls_comm *c, zmls_plan *p, int64_t chunk_ch)
 {
     if (!c || !p || chunk_ch < 1) { set_error("bad reserve arguments"); return ZMLS_E_ARG; }
     if (p->device != c->device) { set_error("plan is on device %d, communicator on device %d", p->device, c->device); return ZMLS_E_ARG; }
-    int rc = use_device(c->device);
-    if (rc) return rc;
+    ZDEVICE(c->device);
+    int rc = ZMLS_OK;
     rc = zmls_plan_reserve(p, chunk_ch);
     if (rc) return rc;
     const size_t recv = (size_t)p->L * (size_t)chunk_ch * dtype_size(p->dtype);
@@ -200,8 +201,8 @@ int zmls_comm_reduce_scatter_device(zmls_comm *c, const void *d_send, void *d_re
 {
     if (!c || !d_send || !d_recv || recv_count < 1) { set_error("bad reduce_scatter arguments"); return ZMLS_E_ARG; }
     if (dtype != ZMLS_F64 && dtype != ZMLS_F32) { set_error("reduce_scatter moves f64 or f32"); return ZMLS_E_ARG; }
-    int rc = use_device(c->device);
-    if (rc) return rc;
+    ZDEVICE(c->device);
+    int rc = ZMLS_OK;
     Rccl *R = rccl();
     if (!R) return ZMLS_E_COMM;
     ZNCCL(R, R->ReduceScatter(d_send, d_recv, (size_t)recv_count, nccl_type(dtype), ncclSum, c->nccl, (hipStream_t)stream));
@@ -212,8 +213,8 @@ int zmls_comm_all_gather_device(zmls_comm *c, const void *d_send, void *d_recv, 
 {
     if (!c || !d_send || !d_recv || send_count < 1) { set_error("bad all_gather arguments"); return ZMLS_E_ARG; }
     if (dtype != ZMLS_F64 && dtype != ZMLS_F32) { set_error("all_gather moves f64 or f32"); return ZMLS_E_ARG; }
-    int rc = use_device(c->device);
-    if (rc) return rc;
+    ZDEVICE(c->device);
+    int rc = ZMLS_OK;
     Rccl *R = rccl();
     if (!R) return ZMLS_E_COMM;
     ZNCCL(R, R->AllGather(d_send, d_recv, (size_t)send_count, nccl_type(dtype), c->nccl, (hipStream_t)stream));
@@ -231,8 +232,8 @@ int zmls_period_sum_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t 
         return ZMLS_E_ARG;
     }
     if (row_stride < 1 || ch_stride < 1 || n_blocks < 1 || block_ch_stride < 0 || ch_first < 0 || block_ch < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
-    int rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
     return launch_period_sum(d_x, in_dtype, p->dtype, p->L, n_rows / p->L - skip_periods, skip_periods, row_stride, ch_stride, n_blocks,
                              block_ch_stride, ch_first, block_ch, -1, d_out, (hipStream_t)stream);
 }
@@ -262,8 +263,8 @@ int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d
     if (n_ch < 1 || n_ch % c->n_ranks) { set_error("%lld channels do not split evenly over %d ranks", (long long)n_ch, c->n_ranks); return ZMLS_E_ARG; }
     if (row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("strides must be positive"); return ZMLS_E_ARG; }
     if (c->chunk_ch < 1 || c->staging_dtype != p->dtype || c->staging_L != p->L) { set_error("call zmls_comm_reserve(comm, plan, chunk_channels) first"); return ZMLS_E_WORKSPACE; }
-    int rc = use_device(c->device);
-    if (rc) return rc;
+    ZDEVICE(c->device);
+    int rc = ZMLS_OK;
     Rccl *R = rccl();
     if (!R) return ZMLS_E_COMM;
     hipStream_t st = (hipStream_t)stream;

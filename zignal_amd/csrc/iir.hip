@@ -10,7 +10,10 @@
 //   chunk kernel (pass 1): a workgroup loads a chunk (8192 samples: 256 sub-blocks of 32) into LDS with coalesced
 //       reads, every thread runs its sub-block from zero, an in-LDS scan with A^32, A^64, ... gives the chunk's
 //       zero-state end state;
-//   combine kernel: one thread per channel walks the chunks, s_{c+1} = A^chunk s_c + end_c;
+//   combine: the chunks' start states, s_{c+1} = A^chunk s_c + end_c. Up to 16 chunks: one thread per channel walks
+//       them. More: the same scan once more, one level up - a workgroup scans 256 chunks of one channel in LDS with
+//       A^chunk, A^(2 chunk), ... (group scan kernel), one thread per channel walks the GROUPS (256 times fewer steps),
+//       and a fix-up kernel adds (A^chunk)^t x (group start) to chunk t of every group but the first;
 //   chunk kernel (pass 2): same load and scan, now with the chunk's start state, every thread reruns its sub-block
 //       from its true start state and the chunk is written back coalesced.
 // Same arithmetic per sample as lfilter (same operation order inside a sub-block); the start states differ from
@@ -26,7 +29,9 @@ namespace zmls {
 
 constexpr int kIirSub = 32;        // samples per thread
 constexpr int kIirMaxS = 8;        // largest state size (filter order) built
-constexpr int kIirLevels = 9;      // P[d] = A^(32 * 2^d), d = 0..8
+constexpr int kIirLevels = 17;     // P[d] = A^(32 * 2^d), d = 0..16: runs (d < 8), chunks of 2^4 or 2^8 runs, groups of 2^8 chunks
+constexpr int kIirGroup = 256;     // chunks per group of the second-level scan
+constexpr int kIirSerialChunks = 16;   // up to here one thread per channel walks the chunks
 constexpr int kIirPitch = kIirSub + 1;
 
 struct IirDev {
@@ -205,9 +210,75 @@ __global__ void __launch_bounds__(64) iir_combine_kernel(const IirDev *__restric
     }
 }
 
+// second level of the start-state assembly: blockIdx = group * n_ch + channel; thread t holds chunk group*256 + t.
+// Writes the chunks' start states as if the group started at rest (exclusive scan) and the group's own end state.
+template <int S>
+__global__ void __launch_bounds__(kIirGroup) iir_group_scan_kernel(const IirDev *__restrict__ f, int level, int64_t n_chunks, int64_t n_ch,
+                                                                   const double *__restrict__ zc, double *__restrict__ sin, double *__restrict__ zg)
+{
+    __shared__ double sc[kIirGroup * S];
+    const int tid = threadIdx.x;
+    const int64_t c = blockIdx.x % n_ch, g = blockIdx.x / n_ch;
+    const int64_t q = g * kIirGroup + tid;
+    double v[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) v[k] = q < n_chunks ? zc[(q * n_ch + c) * S + k] : 0.0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) sc[tid * S + k] = v[k];
+        __syncthreads();
+        if (tid >= (1 << d)) {
+            double u[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) u[k] = sc[(tid - (1 << d)) * S + k];
+            matvec_acc<S>(f->P[level + d], u, v);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) sc[tid * S + k] = v[k];
+    __syncthreads();
+    if (q < n_chunks) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) sin[(q * n_ch + c) * S + k] = tid ? sc[(tid - 1) * S + k] : 0.0;
+    }
+    if (tid == kIirGroup - 1) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) zg[(g * n_ch + c) * S + k] = v[k];
+    }
+}
+
+// chunk t of group g >= 1 starts from (A^chunk)^t x (start state of the group) on top of what the group scan wrote
+template <int S>
+__global__ void __launch_bounds__(256) iir_group_fix_kernel(const IirDev *__restrict__ f, int level, int64_t n_chunks, int64_t n_ch,
+                                                            const double *__restrict__ sg, double *__restrict__ sin)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + (int64_t)kIirGroup * n_ch;     // group 0 starts at rest
+    if (idx >= n_chunks * n_ch) return;
+    const int64_t q = idx / n_ch, c = idx % n_ch, g = q / kIirGroup;
+    const int t = (int)(q % kIirGroup);
+    double w[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) w[k] = sg[(g * n_ch + c) * S + k];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        if ((t >> d) & 1) {
+            double r[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) r[k] = 0.0;
+            matvec_acc<S>(f->P[level + d], w, r);
+#pragma unroll
+            for (int k = 0; k < S; ++k) w[k] = r[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) sin[idx * S + k] += w[k];
+}
+
 template <int S, int CC>
 int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs, double *d_zc, double *d_sin,
-                 double *d_y, int64_t ors, int64_t ocs, hipStream_t st)
+                 double *d_zg, double *d_sg, double *d_y, int64_t ors, int64_t ocs, hipStream_t st)
 {
     constexpr int NB = 256 / CC, TT = NB * kIirSub, LOGNB = (CC == 1) ? 8 : 4;
     const uint64_t n_cgrp = (uint64_t)((n_ch + CC - 1) / CC), n_chunks = (uint64_t)((n_rows + TT - 1) / TT);
@@ -215,8 +286,22 @@ int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_row
     if (blocks == 0 || blocks > 0x7FFFFFFFull) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
     hipLaunchKernelGGL((iir_chunk_kernel<S, CC, false>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, n_rows, n_ch, rs, cs,
                        (uint32_t)n_cgrp, d_zc, (const double *)nullptr, (double *)nullptr, ors, ocs);
-    hipLaunchKernelGGL(iir_combine_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
-                       (const double *)d_zc, d_sin);
+    if (n_chunks <= (uint64_t)kIirSerialChunks) {
+        hipLaunchKernelGGL(iir_combine_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
+                           (const double *)d_zc, d_sin);
+    } else {
+        const uint64_t n_groups = (n_chunks + kIirGroup - 1) / kIirGroup;
+        if (n_groups * (uint64_t)n_ch > 0x7FFFFFFFull) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
+        hipLaunchKernelGGL(iir_group_scan_kernel<S>, dim3((uint32_t)(n_groups * n_ch)), dim3(kIirGroup), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
+                           (const double *)d_zc, d_sin, d_zg);
+        if (n_groups > 1) {
+            hipLaunchKernelGGL(iir_combine_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB + 8, (int64_t)n_groups, n_ch,
+                               (const double *)d_zg, d_sg);
+            const uint64_t rest = (n_chunks - kIirGroup) * (uint64_t)n_ch;
+            hipLaunchKernelGGL(iir_group_fix_kernel<S>, dim3((uint32_t)((rest + 255) / 256)), dim3(256), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
+                               (const double *)d_sg, d_sin);
+        }
+    }
     hipLaunchKernelGGL((iir_chunk_kernel<S, CC, true>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, n_rows, n_ch, rs, cs,
                        (uint32_t)n_cgrp, (double *)nullptr, (const double *)d_sin, d_y, ors, ocs);
     ZHIP(hipGetLastError());
@@ -225,10 +310,10 @@ int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_row
 
 template <int S>
 int launch_iir_cc(bool time_contiguous, const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs,
-                  double *d_zc, double *d_sin, double *d_y, int64_t ors, int64_t ocs, hipStream_t st)
+                  double *d_zc, double *d_sin, double *d_zg, double *d_sg, double *d_y, int64_t ors, int64_t ocs, hipStream_t st)
 {
-    if (time_contiguous) return launch_iir_s<S, 1>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_y, ors, ocs, st);
-    return launch_iir_s<S, 16>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_y, ors, ocs, st);
+    if (time_contiguous) return launch_iir_s<S, 1>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, st);
+    return launch_iir_s<S, 16>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, st);
 }
 
 // A^k of the SxS state matrix by squaring, in long double
@@ -251,8 +336,9 @@ struct zmls_iir {
     int device;
     int S;
     zmls::IirDev *d_f;
-    double *d_zc, *d_sin;
-    size_t scratch_elems;      // each
+    double *d_zc, *d_sin;      // zero-state end state / start state of every chunk
+    double *d_zg, *d_sg;       // the same of every group of 256 chunks (1/256 of the above)
+    size_t scratch_elems;      // of d_zc, d_sin each
 };
 
 using namespace zmls;
@@ -267,8 +353,8 @@ int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, in
     int S = (nb > na ? nb : na) - 1;
     if (S > kIirMaxS) { set_error("filter order %d is beyond the %d built for the device", S, kIirMaxS); return ZMLS_E_UNSUPPORTED; }
     if (S < 1) S = 1;           // a pure gain runs as a first-order filter with zero taps
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     IirDev h;
     memset(&h, 0, sizeof h);
     for (int i = 0; i < nb; ++i) h.b[i] = b[i] / a[0];     // lfilter normalises by a[0]
@@ -305,10 +391,13 @@ int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, in
 int zmls_iir_destroy(zmls_iir *f)
 {
     if (!f) return ZMLS_OK;
-    if (hipSetDevice(f->device) == hipSuccess) {
+    DeviceScope on_device(f->device);
+    if (!on_device.rc) {
         if (f->d_f) (void)hipFree(f->d_f);
         if (f->d_zc) (void)hipFree(f->d_zc);
         if (f->d_sin) (void)hipFree(f->d_sin);
+        if (f->d_zg) (void)hipFree(f->d_zg);
+        if (f->d_sg) (void)hipFree(f->d_sg);
     }
     free(f);
     return ZMLS_OK;
@@ -318,16 +407,21 @@ int zmls_iir_destroy(zmls_iir *f)
 int zmls_iir_reserve(zmls_iir *f, int64_t n_rows, int64_t n_ch)
 {
     if (!f || n_rows < 1 || n_ch < 1) { set_error("bad reserve arguments"); return ZMLS_E_ARG; }
-    int rc = use_device(f->device);
-    if (rc) return rc;
+    ZDEVICE(f->device);
+    int rc = ZMLS_OK;
     const int64_t tt = (256 / 16) * kIirSub;                                   // the shorter chunk (frame-major tiles)
     const size_t need = (size_t)((n_rows + tt - 1) / tt) * (size_t)n_ch * (size_t)f->S;
     if (need <= f->scratch_elems) return ZMLS_OK;
     if (f->d_zc) { ZHIP(hipFree(f->d_zc)); f->d_zc = nullptr; }
     if (f->d_sin) { ZHIP(hipFree(f->d_sin)); f->d_sin = nullptr; }
+    if (f->d_zg) { ZHIP(hipFree(f->d_zg)); f->d_zg = nullptr; }
+    if (f->d_sg) { ZHIP(hipFree(f->d_sg)); f->d_sg = nullptr; }
     f->scratch_elems = 0;
+    const size_t need_g = (size_t)(((n_rows + tt - 1) / tt + kIirGroup - 1) / kIirGroup) * (size_t)n_ch * (size_t)f->S;
     ZHIP(hipMalloc((void **)&f->d_zc, need * 8));
     ZHIP(hipMalloc((void **)&f->d_sin, need * 8));
+    ZHIP(hipMalloc((void **)&f->d_zg, need_g * 8));
+    ZHIP(hipMalloc((void **)&f->d_sg, need_g * 8));
     f->scratch_elems = need;
     return ZMLS_OK;
 }
@@ -338,14 +432,14 @@ int zmls_iir_device(zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, 
     if (!f || !d_x || !d_y) { set_error("null argument"); return ZMLS_E_ARG; }
     if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
     if (n_rows < 1 || n_ch < 1 || row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
-    int rc = use_device(f->device);
-    if (rc) return rc;
+    ZDEVICE(f->device);
+    int rc = ZMLS_OK;
     const bool tc = row_stride == 1 && (n_ch == 1 || ch_stride != 1);
     const int64_t tt = (256 / (tc ? 1 : 16)) * kIirSub;
     const size_t need = (size_t)((n_rows + tt - 1) / tt) * (size_t)n_ch * (size_t)f->S;
     if (need > f->scratch_elems) { set_error("filter scratch holds %zu chunk states, %zu needed: call zmls_iir_reserve first", f->scratch_elems, need); return ZMLS_E_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
-#define ZIIR(SS) case SS: return launch_iir_cc<SS>(tc, f->d_f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, f->d_zc, f->d_sin, d_y, out_row_stride, out_ch_stride, st);
+#define ZIIR(SS) case SS: return launch_iir_cc<SS>(tc, f->d_f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, f->d_zc, f->d_sin, f->d_zg, f->d_sg, d_y, out_row_stride, out_ch_stride, st);
     switch (f->S) {
         ZIIR(1) ZIIR(2) ZIIR(3) ZIIR(4) ZIIR(5) ZIIR(6) ZIIR(7) ZIIR(8)
     default: break;

@@ -10,16 +10,19 @@
 // gather table Q[s(n)] = n. The dual (Galois) register C[k+1] = x*C[k] mod p(x), C[0] = 1, gives
 // Pl[m] = C[(L-m) mod L] and with it the scatter table M[C[k]] = (L-k) mod L.
 //
-// Parallelism: thread t owns bits [1024 t, 1024 t + 1024). It jumps to its start state with
-// GF(2) matrix powers F^(2^k) (built on the host, zmls_host.cpp) and then steps 32 bits per
-// output word. Integer VALU only; the output is tiny (2 MiB of bits, 2 x 64 MiB of tables at
-// N = 24) and is written once per plan.
+// Parallelism: thread t owns bits [128 t, 128 t + 128). It jumps to its start state with
+// GF(2) matrix powers F^(2^k) (built on the host, zmls_host.cpp; any start costs the same ~2N
+// matrix-vector products, so short runs are free) and then steps 32 bits per output word: N=20 is
+// 8192 threads (every CU busy) instead of the 1024 a 1024-bit run gave. Integer VALU only; the
+// output is tiny (2 MiB of bits, 2 x 64 MiB of tables at N = 24) and is written once per plan.
+// Orders 31 and 32 (the end of zignal's tap table) get the bit sequence only: gather / scatter_nat
+// are null there (zmls_plan_create explains why).
 #include "zmls_internal.h"
 
 namespace zmls {
 namespace {
 
-constexpr int kBitsPerThread = 1024;
+constexpr int kBitsPerThread = 128;
 
 __global__ void __launch_bounds__(256) lfsr_tables_kernel(int N, uint32_t G, uint32_t s0, const JumpTables *__restrict__ jt,
                                                           uint32_t *__restrict__ bits, uint64_t n_words,
@@ -32,8 +35,9 @@ __global__ void __launch_bounds__(256) lfsr_tables_kernel(int N, uint32_t G, uin
 
     uint32_t s = s0;      // window at n = 0
     uint32_t c = 1u;      // C[0]
+    const uint64_t jump = n0 % L;         // the registers have period L; the bit buffer runs a little past it (and past 2^32 at N = 32)
     for (int k = 0; k < 32; ++k)
-        if ((n0 >> k) & 1ull) {
+        if ((jump >> k) & 1ull) {
             s = gf2_apply(jt->fib[k], s, N);
             c = gf2_apply(jt->gal[k], c, N);
         }
@@ -41,7 +45,7 @@ __global__ void __launch_bounds__(256) lfsr_tables_kernel(int N, uint32_t G, uin
         uint32_t word = 0;
         for (int j = 0; j < 32; ++j) {
             const uint64_t n = n0 + (uint64_t)w * 32 + j;
-            if (n < L) {
+            if (n < L && gather) {
                 gather[s] = (uint32_t)n;
                 scatter_nat[c] = (n == 0) ? 0u : (uint32_t)(L - n);
             }

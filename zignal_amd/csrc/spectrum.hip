@@ -106,8 +106,8 @@ int zmls_spectrum_create(zmls_spectrum **out, int64_t n_samples, int64_t n_ch, i
     if (!out) { set_error("null argument"); return ZMLS_E_ARG; }
     *out = nullptr;
     if (n_samples < 2 || n_ch < 1 || n_samples >= ((int64_t)1 << 31) - 1) { set_error("bad spectrum size"); return ZMLS_E_ARG; }
-    int rc = use_device(device);
-    if (rc) return rc;
+    ZDEVICE(device);
+    int rc = ZMLS_OK;
     HipFft *F = hipfft();
     if (!F) return ZMLS_E_UNSUPPORTED;
     zmls_spectrum *s = (zmls_spectrum *)calloc(1, sizeof(zmls_spectrum));
@@ -139,7 +139,8 @@ int zmls_spectrum_create(zmls_spectrum **out, int64_t n_samples, int64_t n_ch, i
 int zmls_spectrum_destroy(zmls_spectrum *s)
 {
     if (!s) return ZMLS_OK;
-    if (hipSetDevice(s->device) == hipSuccess) {
+    DeviceScope on_device(s->device);
+    if (!on_device.rc) {
         HipFft *F = hipfft();
         if (F && s->plan) (void)F->Destroy(s->plan);
         if (s->d_stage) (void)hipFree(s->d_stage);
@@ -161,8 +162,8 @@ int zmls_spectrum_device(zmls_spectrum *s, const double *d_h, int64_t row_stride
 {
     if (!s || !d_h || !d_mag) { set_error("null argument"); return ZMLS_E_ARG; }
     if (row_stride < 1 || ch_stride < 1) { set_error("strides must be positive"); return ZMLS_E_ARG; }
-    int rc = use_device(s->device);
-    if (rc) return rc;
+    ZDEVICE(s->device);
+    int rc = ZMLS_OK;
     HipFft *F = hipfft();
     if (!F) return ZMLS_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -182,8 +183,8 @@ int zmls_spectrum_device(zmls_spectrum *s, const double *d_h, int64_t row_stride
 int zmls_spectrum_host(zmls_spectrum *s, const double *h, const double *window, int normalise, double *mag)
 {
     if (!s || !h || !mag) { set_error("null argument"); return ZMLS_E_ARG; }
-    int rc = use_device(s->device);
-    if (rc) return rc;
+    ZDEVICE(s->device);
+    int rc = ZMLS_OK;
     double *d_h = nullptr, *d_w = nullptr, *d_m = nullptr;
     const size_t hb = (size_t)s->n * s->n_ch * 8, mb = (size_t)s->n_bins * s->n_ch * 8;
     hipError_t e = hipMalloc((void **)&d_h, hb);

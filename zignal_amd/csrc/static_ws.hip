@@ -62,8 +62,7 @@ extern "C" int zmls_impulse_device_static(zmls_plan *p, const void *d_x, int in_
     int64_t periods = 0;
     int rc = capture_periods(p, n_rows, &periods);
     if (rc) return rc;
-    rc = use_device(p->device);
-    if (rc) return rc;
+    ZDEVICE(p->device);
     void *ws = nullptr;
     size_t ws_bytes = 0;
     rc = static_workspace(p->device, &ws, &ws_bytes);       // resolved by zmls_plan_create; here it is a table look-up

@@ -4,11 +4,17 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/zmls.h"
+#include "../../include/zmls_testing.h"
 #include "geometry.h"
 
 namespace zmls {
 
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
+// zignal's tap table ends at N = 32 (mlstaps.py). The bit sequence is generated for all of it; impulse responses
+// (permutation tables + transform) up to N = 30: one 64-byte-row slab of the intermediate of a 2^31-point transform
+// is 137 GB, of a 2^32-point one 275 GB, next to 16 / 32 GiB of tables and the capture itself in 288 GB of HBM.
+constexpr int kMaxTransformOrder = 30;
+constexpr int kMaxSequenceOrder = 32;
 constexpr int kSynthTaps = 16;
 
 // tile configurations (geometry.h). CFG_SMALL is the general one (any channel count, any strides,
@@ -53,6 +59,7 @@ struct JumpTables {
 };
 void build_jump_tables(int N, uint32_t G, JumpTables *jt);            // host
 uint32_t host_fib_state(int N, uint32_t G, const JumpTables &jt, uint64_t steps);
+bool period_is_maximal(int N, const JumpTables &jt);                  // host; used where no tables are built
 
 // ---- pass launch description
 enum InMode { IN_WORK = 0, IN_GATHER_VEC = 1, IN_GATHER_ELEM = 2 };
@@ -96,10 +103,32 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
                int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms, int gather_pass_only,
                void *work, size_t work_bytes);
 int capture_periods(const zmls_plan *p, int64_t n_rows, int64_t *periods);
+int sequence_only(const zmls_plan *p);      // ZMLS_E_UNSUPPORTED for the plans of orders 31, 32 (no tables, no transform)
 // the library's static device workspace (static_ws.hip): resolved once per device, at plan creation
 int static_workspace(int device, void **ptr, size_t *bytes);
+// capture placement search (zmls_host.cpp): host logic over callbacks
+struct PlacementOps {
+    void *ctx;
+    void *(*alloc)(void *ctx);                      // a new candidate buffer, or null when memory is full
+    void (*release)(void *ctx, void *buf);
+    int (*rate)(void *ctx, void *buf, float *ms);   // gather-pass milliseconds on this buffer
+};
+struct PlacementStats { int candidates; float first_ms, final_ms, model_ms; int rounds, alloc_failed; };
+int placement_search(const PlacementOps &ops, int tries, double model_ms, void **out, PlacementStats *stats);
 size_t dtype_size(int dt);
 int use_device(int device);
+struct DeviceScope {
+    int prev = -1, rc = 0;
+    explicit DeviceScope(int device);
+    ~DeviceScope();
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define ZCAT2(a, b) a##b
+#define ZCAT(a, b) ZCAT2(a, b)
+#define ZDEVICE(dev)                                          \
+    ::zmls::DeviceScope ZCAT(zscope_, __LINE__)(dev);         \
+    if (ZCAT(zscope_, __LINE__).rc) return ZCAT(zscope_, __LINE__).rc
 hipError_t settled_malloc(void **ptr, size_t bytes);
 
 int launch_pass_f64(int cfg, int K, int inm, int outm, const PassArgs &a, hipStream_t st);

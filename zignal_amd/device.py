@@ -96,14 +96,21 @@ class Plan:
         if staging:
             L.check(L.lib().zmls_plan_reserve_staging(self._h, int(n_ch)))
 
-    def alloc_capture(self, n_rows, n_ch, dtype_code=None, tries=0):
+    def alloc_capture(self, n_rows, n_ch, dtype_code=None, tries=0, stats=False):
         """DeviceBuffer for an (n_rows, n_ch) C-contiguous capture, placed where this plan's gather pass reads it
-        fastest (zmls_capture_alloc). Returns (buffer, gather-pass milliseconds of the chosen placement or 0)."""
+        fastest (zmls_capture_alloc). Returns (buffer, gather-pass milliseconds of the chosen placement or 0); with
+        stats=True the second item is a dict instead: candidates_tried (0: nothing to choose, plainly allocated),
+        plain_alloc_gather_ms (the first candidate = what one hipMalloc gives in this process), chosen_ms, model_ms
+        (what the pass should take on a good placement), rounds, memory_full (an allocation failed during the search)."""
         code = self.dtype_code if dtype_code is None else dtype_code
-        p, ms = ctypes.c_void_p(), ctypes.c_float()
-        L.check(L.lib().zmls_capture_alloc(self._h, code, int(n_rows), int(n_ch), int(tries), ctypes.byref(p), ctypes.byref(ms)))
+        p, st = ctypes.c_void_p(), (ctypes.c_float * 8)()
+        L.check(L.lib().zmls_capture_alloc_stats(self._h, code, int(n_rows), int(n_ch), int(tries), ctypes.byref(p), st))
         nbytes = int(n_rows) * int(n_ch) * np.dtype(L.NP_OF[code]).itemsize
-        return DeviceBuffer(nbytes, self.device, _ptr=p.value), ms.value
+        buf = DeviceBuffer(nbytes, self.device, _ptr=p.value)
+        if not stats:
+            return buf, st[2]
+        return buf, {"candidates_tried": int(st[0]), "plain_alloc_gather_ms": st[1], "chosen_ms": st[2], "model_ms": st[3],
+                     "rounds": int(st[4]), "memory_full": bool(st[5])}
 
     # -- sequence
     def bits_packed(self, nbits=None):
