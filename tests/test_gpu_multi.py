@@ -65,6 +65,59 @@ def test_two_emulated_ranks_step_by_step(N, C, R, dtype):
         assert rel_err(h, want_h[:, first:first + n]) <= tol
 
 
+@pytest.mark.parametrize("P,chunk", [(2, 3), (4, 2), (8, 1)])
+def test_period_sums_in_the_exchange_layout_chunk_by_chunk(P, chunk):
+    """What the fused entry point asks of zmls_period_sum_device on P > 1 ranks: P channel blocks per call, a chunk of
+    each block's channels at a time (n_blocks = P, block stride = share, ch_first = k * chunk): block q of the send
+    buffer must hold the sums of channels q*share + k*chunk ... of this rank's periods."""
+    N, R = 10, 5
+    taps = TAPS[N][0]
+    p = plan(N, taps)
+    L = p.L
+    share = 8
+    C = P * share
+    rng = np.random.default_rng(P)
+    x = rng.standard_normal((R * L, C))
+    d_x = DeviceBuffer(x.nbytes).upload(x)
+    want = x[L:].reshape(R - 1, L, C).sum(axis=0)
+    for k in range((share + chunk - 1) // chunk):
+        cc = min(chunk, share - k * chunk)
+        d_s = DeviceBuffer(P * L * cc * 8)
+        d_s.fill(0xFF)
+        multi.period_sum_device(p, d_x.ptr, _lib.ZMLS_F64, R * L, 1, C, 1, P, share, k * chunk, cc, d_s.ptr)
+        got = d_s.download((P, L, cc), np.float64)
+        for q in range(P):
+            assert np.allclose(got[q], want[:, q * share + k * chunk:q * share + k * chunk + cc], rtol=0, atol=1e-12), (k, q)
+        d_s.free()
+    d_x.free()
+
+
+def test_two_ranks_on_two_gpus_over_rccl():
+    """The fused period-sharded entry point with a real two-rank communicator: needs two GPUs (the driver's multi-GPU
+    node; a one-GPU test box skips it - RCCL refuses two ranks on one device). Each rank is a process of its own
+    (tests/rccl_rank_worker.py), the id travels through a file, the result is held to zmls_impulse_device."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    if _lib.device_count() < 2:
+        pytest.skip("one GPU: RCCL needs a device per rank (parity of the P > 1 exchange is unpinned on this box)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "rccl_rank_worker.py"), str(r), "2", os.path.join(tmp, "id.bin")],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        outs = []
+        for pr in procs:
+            try:
+                outs.append(pr.communicate(timeout=240)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+    for r, (pr, out) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0 and "rank %d ok" % r in out, out[-3000:]
+
+
 def test_rccl_collectives_on_a_one_rank_communicator(comm1):
     a = np.arange(1000, dtype=np.float64)
     d_a, d_b = DeviceBuffer(a.nbytes).upload(a), DeviceBuffer(a.nbytes)

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libzmls.so")
+# $ZMLS_LIBRARY: another build of the same library (tuning: A/B runs of two builds on one box)
+LIB_PATH = os.environ.get("ZMLS_LIBRARY") or os.path.join(_HERE, "lib", "libzmls.so")
 
 ZMLS_F64, ZMLS_F32, ZMLS_I16, ZMLS_I32 = 0, 1, 2, 3
 E_ARG, E_HIP, E_NODEVICE, E_WORKSPACE, E_UNSUPPORTED, E_COMM = -1, -2, -3, -4, -5, -6

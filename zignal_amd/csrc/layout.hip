@@ -49,21 +49,23 @@ __global__ void __launch_bounds__(256) sum_transpose_kernel(const TIN *__restric
         src[i] = x + (ok[i] ? ch : 0) * ch_stride + (int64_t)skip * L + (ok[i] ? j : 0);
         acc[i] = (T)0;
     }
+    // the capture is read exactly once: non-temporal loads, DEPTH periods of them in flight per lane
+    constexpr int DEPTH = 4;
     int p = 0;
-    for (; p + 2 <= periods; p += 2) {                        // two periods of loads in flight per lane
-        TIN t[CPW], w[CPW];
+    for (; p + DEPTH <= periods; p += DEPTH) {
+        TIN t[DEPTH][CPW];
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) t[i] = src[i][(int64_t)p * L];
+        for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) w[i] = src[i][(int64_t)(p + 1) * L];
+            for (int i = 0; i < CPW; ++i) t[d][i] = __builtin_nontemporal_load(src[i] + (int64_t)(p + d) * L);
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) acc[i] += (T)t[i];     // period order, as numpy adds the rows
+        for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) acc[i] += (T)w[i];
+            for (int i = 0; i < CPW; ++i) acc[i] += (T)t[d][i];     // period order, as numpy adds the rows
     }
-    if (p < periods) {
+    for (; p < periods; ++p) {
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) acc[i] += (T)src[i][(int64_t)p * L];
+        for (int i = 0; i < CPW; ++i) acc[i] += (T)__builtin_nontemporal_load(src[i] + (int64_t)p * L);
     }
 #pragma unroll
     for (int i = 0; i < CPW; ++i) tile[lane][wave * CPW + i] = ok[i] ? acc[i] : (T)0;

@@ -10,10 +10,10 @@
 // gather table Q[s(n)] = n. The dual (Galois) register C[k+1] = x*C[k] mod p(x), C[0] = 1, gives
 // Pl[m] = C[(L-m) mod L] and with it the scatter table M[C[k]] = (L-k) mod L.
 //
-// Parallelism: thread t owns bits [128 t, 128 t + 128). It jumps to its start state with
+// Parallelism: thread t owns bits [64 t, 64 t + 64). It jumps to its start state with
 // GF(2) matrix powers F^(2^k) (built on the host, zmls_host.cpp; any start costs the same ~2N
 // matrix-vector products, so short runs are free) and then steps 32 bits per output word: N=20 is
-// 8192 threads (every CU busy) instead of the 1024 a 1024-bit run gave. Integer VALU only; the
+// 16384 threads in 256 one-wave workgroups (every CU busy) instead of the 1024 threads a 1024-bit run gave. Integer VALU only; the
 // output is tiny (2 MiB of bits, 2 x 64 MiB of tables at N = 24) and is written once per plan.
 // Orders 31 and 32 (the end of zignal's tap table) get the bit sequence only: gather / scatter_nat
 // are null there (zmls_plan_create explains why).
@@ -22,9 +22,10 @@
 namespace zmls {
 namespace {
 
-constexpr int kBitsPerThread = 128;
+constexpr int kBitsPerThread = 64;
+constexpr int kLfsrBlock = 64;      // one wave per workgroup: N=20 is 256 workgroups, one per CU
 
-__global__ void __launch_bounds__(256) lfsr_tables_kernel(int N, uint32_t G, uint32_t s0, const JumpTables *__restrict__ jt,
+__global__ void __launch_bounds__(kLfsrBlock) lfsr_tables_kernel(int N, uint32_t G, uint32_t s0, const JumpTables *__restrict__ jt,
                                                           uint32_t *__restrict__ bits, uint64_t n_words,
                                                           uint32_t *__restrict__ gather, uint32_t *__restrict__ scatter_nat)
 {
@@ -176,8 +177,8 @@ int launch_lfsr_tables(int N, uint32_t G, uint32_t s0, const JumpTables *d_jt, u
                        uint32_t *d_gather, uint32_t *d_scatter_nat, hipStream_t st)
 {
     const uint64_t threads = (n_words * 32 + kBitsPerThread - 1) / kBitsPerThread;
-    const uint32_t blocks = (uint32_t)((threads + 255) / 256);
-    hipLaunchKernelGGL(lfsr_tables_kernel, dim3(blocks), dim3(256), 0, st, N, G, s0, d_jt, d_bits, n_words, d_gather, d_scatter_nat);
+    const uint32_t blocks = (uint32_t)((threads + kLfsrBlock - 1) / kLfsrBlock);
+    hipLaunchKernelGGL(lfsr_tables_kernel, dim3(blocks), dim3(kLfsrBlock), 0, st, N, G, s0, d_jt, d_bits, n_words, d_gather, d_scatter_nat);
     ZHIP(hipGetLastError());
     return ZMLS_OK;
 }
