@@ -208,6 +208,17 @@ int zmls_iir_reserve(zmls_iir *f, int64_t n_rows, int64_t n_ch);
  * Enqueues three kernels on hip_stream; never allocates or synchronises. */
 int zmls_iir_device(zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
                     int64_t ch_stride, double *d_y, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
+/* De-emphasis and impulse response in one: replaces MLS.apply_deemphasis (mls.py:401-407) followed by get_impulse
+ * (mls.py:409-414), the chain MLS_simple.get_impulse runs (mls.py:454-458): h = get_impulse(lfilter(b, a, x)) for n_ch
+ * channels. Filter and average are linear, so the capture is swept ONCE (periods added up, the filter's state at
+ * every period boundary taken beside it) and the filter itself runs over one period of sums from the summed states
+ * (iir.hip): nothing of the capture's size is written. x as in zmls_impulse_device (n_rows = R*L frames, period 0
+ * filtered but not averaged), h in the plan's dtype. zmls_iir_reserve_fused allocates (outside timed regions);
+ * the launch call never allocates or synchronises. */
+int zmls_iir_reserve_fused(zmls_iir *f, zmls_plan *p, int64_t n_rows, int64_t n_ch);
+int zmls_impulse_filtered_device(zmls_plan *p, zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch,
+                                 int64_t row_stride, int64_t ch_stride,
+                                 void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
 /* host buffers: y is (n_rows, n_ch) C-contiguous float64; uploads, filters, downloads, synchronous */
 int zmls_iir_host(zmls_iir *f, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
                   int64_t ch_stride, double *y);

@@ -111,3 +111,109 @@ def test_mls_simple_fused_deemphasis_and_impulse_matches_the_two_steps():
     want = scipy.signal.lfilter(*mls._filter_deemphasis.get_coefficients(), y, axis=0)
     assert rel_err(mls.apply_deemphasis(y), want) <= TOL
     assert abs(k.samples[0, 0] - 1.0) < 1e-3
+
+
+# ---------------------------------------------------------------- de-emphasis fused with the impulse response
+def _fused(plan, iir, x, rs=None, cs=None, host=None):
+    """zmls_impulse_filtered_device on capture x (frames, channels); `host` is the array actually uploaded when the
+    memory layout differs from x's"""
+    n_rows, C = x.shape
+    src = x if host is None else host
+    d_x = DeviceBuffer(src.nbytes).upload(src)
+    d_h = DeviceBuffer(plan.L * C * plan.np_dtype().itemsize)
+    d_h.fill(0xFF)
+    iir.reserve_fused(plan, n_rows, C)
+    plan.impulse_filtered_device(iir, d_x.ptr, _lib.dtype_code(src.dtype), n_rows, C, C if rs is None else rs, 1 if cs is None else cs,
+                                 d_h.ptr, C, 1)
+    sync(0)
+    h = d_h.download((plan.L, C), plan.np_dtype).astype(np.float64)
+    d_x.free()
+    d_h.free()
+    return h
+
+
+def _reference_chain(N, taps, b, a, x):
+    """what the reference does (mls.py:401-414): lfilter over the whole capture, then get_impulse, channel by channel"""
+    from gpu_common import oracle_ir
+    from oracle import c_oracle
+    ref = c_oracle.sequence(N, taps)
+    y = scipy.signal.lfilter(b, a, x.astype(np.float64), axis=0)
+    return np.stack([oracle_ir(N, taps, np.ascontiguousarray(y[:, c:c + 1]), ref) for c in range(x.shape[1])], axis=1)
+
+
+@pytest.mark.parametrize("N,C,R,order", [(5, 3, 4, 2), (6, 16, 2, 1), (8, 5, 6, 3), (10, 32, 3, 2), (12, 7, 5, 4), (13, 48, 4, 8),
+                                         (14, 16, 17, 2), (16, 32, 3, 2), (17, 4, 2, 5)])
+def test_fused_deemphasis_and_impulse_against_lfilter_then_oracle(N, C, R, order):
+    """Short orders on purpose: at N = 5..8 the filter's memory spans several periods (poles up to 0.97: thousands of
+    samples against L = 31..255), so the summed period-boundary states carry most of the answer."""
+    from gpu_common import plan
+    taps = TAPS[N][0]
+    p = plan(N, taps)
+    rng = np.random.default_rng(1000 * N + C)
+    b, a = stable_filter(order, rng)
+    f = IirFilter(b, a, device=0)
+    x = rng.standard_normal((R * p.L, C))
+    want = _reference_chain(N, taps, b, a, x)
+    assert rel_err(_fused(p, f, x), want) <= TOL
+    # the same capture as a stack of single-channel arrays (channels, frames): time-contiguous memory
+    xt = np.ascontiguousarray(x.T)
+    assert rel_err(_fused(p, f, x, rs=1, cs=R * p.L, host=xt), want) <= TOL
+    f.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int16, np.int32])
+def test_fused_path_input_types_and_float32_plan(dtype):
+    from gpu_common import plan
+    N, C, R = 11, 12, 3
+    taps = TAPS[N][1]
+    rng = np.random.default_rng(77)
+    b, a = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=48000).get_coefficients()
+    x = (rng.standard_normal((R * ((1 << N) - 1), C)) * 3000).astype(dtype)
+    want = _reference_chain(N, taps, a, b, x)                       # de-emphasis: the inverse filter
+    f = IirFilter(a, b, device=0)
+    assert rel_err(_fused(plan(N, taps), f, x), want) <= TOL
+    assert rel_err(_fused(plan(N, taps, "f32"), f, x), want) <= 1e-5
+    f.close()
+
+
+def test_fused_path_equals_the_two_device_steps_at_n20():
+    """N=20, 8 channels x 3 periods: against zmls_iir_device followed by zmls_impulse_device on the same buffers"""
+    from gpu_common import plan
+    N, C, R = 20, 8, 3
+    p = plan(N, TAPS[N][0])
+    L = p.L
+    b, a = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=96000).get_coefficients()
+    f = IirFilter(a, b, device=0)
+    d_x, d_y, d_h = DeviceBuffer(R * L * C * 8), DeviceBuffer(R * L * C * 8), DeviceBuffer(L * C * 8)
+    p.synth_device(d_x.ptr, _lib.ZMLS_F64, R, C, C, 1, sigma=1e-2)
+    f.reserve(R * L, C)
+    p.reserve(C)
+    f.filter_device(d_x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, d_y.ptr, C, 1)
+    p.impulse_device(d_y.ptr, _lib.ZMLS_F64, R * L, C, C, 1, d_h.ptr, C, 1)
+    sync(0)
+    two = d_h.download((L, C), np.float64)
+    f.reserve_fused(p, R * L, C)
+    d_h.fill(0xFF)
+    p.impulse_filtered_device(f, d_x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, d_h.ptr, C, 1)
+    sync(0)
+    assert rel_err(d_h.download((L, C), np.float64), two) <= TOL
+    # without the reservation: a clear error, nothing launched
+    f2 = IirFilter(a, b, device=0)
+    with pytest.raises(_lib.ZmlsError) as ei:
+        p.impulse_filtered_device(f2, d_x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, d_h.ptr, C, 1)
+    assert ei.value.code == _lib.E_WORKSPACE
+    for d in (d_x, d_y, d_h):
+        d.free()
+    f.close()
+    f2.close()
+
+
+def test_mls_get_impulses_deemphasised_many_channels():
+    N, R, C = 12, 4, 6
+    b, a = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=48000).get_coefficients()
+    m = MLS(N=N, taps=TAPS[N][0], fs=48000, repeats=R, B=b, A=a, device=0)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((R * m.L, C))
+    got = m.get_impulses_deemphasised(x)
+    assert got.shape == (m.L, C) and got.dtype == np.float64
+    assert rel_err(got, _reference_chain(N, TAPS[N][0], a, b, x)) <= TOL

@@ -53,3 +53,22 @@ for name, args in (("frame-major in/out (fused gather)", (C, 1, C, 1)), ("stacke
     rs, cs, ors, ocs = args
     ms = timed(lambda: p.impulse_device(x.ptr, _lib.ZMLS_F64, R * L, C, rs, cs, h.ptr, ors, ocs), 3)
     print("impulse  %-38s %8.3f ms  %7.0f GB/s algorithmic" % (name, ms, R * L * C * 8 / ms / 1e6), flush=True)
+
+# de-emphasis + impulse response (MLS.apply_deemphasis + get_impulse, mls.py:401-414): the two device steps against the fused call
+y = DeviceBuffer(R * L * C * 8)
+f.reserve(R * L, C)
+two = timed(lambda: (f.filter_device(x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, y.ptr, C, 1),
+                     p.impulse_device(y.ptr, _lib.ZMLS_F64, R * L, C, C, 1, h.ptr, C, 1)), 3)
+y.free()
+f.reserve_fused(p, R * L, C)
+one = timed(lambda: p.impulse_filtered_device(f, x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, h.ptr, C, 1), 3)
+print("de-emphasis + impulse, N=%d x %d channels x %d periods: filter then transform %8.3f ms, fused %8.3f ms (%.0f GB/s of capture read)"
+      % (N, C, R, two, one, R * L * C * 8 / one / 1e6), flush=True)
+x1 = DeviceBuffer(R * L * 8); x1.fill(0)
+h1 = DeviceBuffer(L * 8)
+f.reserve(R * L, 1); f.reserve_fused(p, R * L, 1)
+y1 = DeviceBuffer(R * L * 8)
+two = timed(lambda: (f.filter_device(x1.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, y1.ptr, 1, 1),
+                     p.impulse_device(y1.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, h1.ptr, 1, 1)), 5)
+one = timed(lambda: p.impulse_filtered_device(f, x1.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, h1.ptr, 1, 1), 5)
+print("de-emphasis + impulse, N=%d, one channel x %d periods (the reference's shape): filter then transform %8.3f ms, fused %8.3f ms" % (N, R, two, one), flush=True)

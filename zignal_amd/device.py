@@ -184,6 +184,13 @@ class Plan:
         L.check(L.lib().zmls_impulse_device(self._h, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride,
                                             d_h, out_row_stride, out_ch_stride, stream))
 
+    def impulse_filtered_device(self, iir, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h,
+                                out_row_stride, out_ch_stride, stream=None):
+        """get_impulse(lfilter(b, a, x)) in one: MLS.apply_deemphasis + get_impulse (mls.py:401-414) without the filtered
+        capture ever being written (zmls_impulse_filtered_device). `iir.reserve_fused(plan, n_rows, n_ch)` first."""
+        L.check(L.lib().zmls_impulse_filtered_device(self._h, iir._h, d_x, in_dtype, int(n_rows), int(n_ch), int(row_stride),
+                                                     int(ch_stride), d_h, int(out_row_stride), int(out_ch_stride), stream))
+
     def impulse_device_timed(self, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h,
                              out_row_stride, out_ch_stride, stream=None):
         """Same launches with HIP events around every pass kernel; returns [ms per pass]."""
@@ -231,6 +238,10 @@ class IirFilter:
 
     def reserve(self, n_rows, n_ch):
         L.check(L.lib().zmls_iir_reserve(self._h, int(n_rows), int(n_ch)))
+
+    def reserve_fused(self, plan, n_rows, n_ch):
+        """scratch for Plan.impulse_filtered_device on captures of n_rows frames x n_ch channels (zmls_iir_reserve_fused)"""
+        L.check(L.lib().zmls_iir_reserve_fused(self._h, plan._h, int(n_rows), int(n_ch)))
 
     def filter_host(self, x):
         """x: (n,) or (n, C) ndarray -> float64 array of the same shape, filtered along axis 0."""

@@ -218,29 +218,50 @@ class MLS(_MLS_base, Audio):
         return self._iir('d').filter_host(np.asarray(x))
 
     def _get_impulse_deemphasised(self, x):
-        """apply_deemphasis followed by get_impulse without the capture leaving the GPU in between
-        (what MLS_simple.get_impulse does, mls.py:454-458): upload x, filter, transform, download the response."""
+        """apply_deemphasis followed by get_impulse (what MLS_simple.get_impulse does, mls.py:454-458) as one device
+        call: upload x, zmls_impulse_filtered_device (the capture is swept once; the filter runs over one period of
+        sums from the summed period-boundary states), download the response."""
         x = np.asarray(x)
         assert len(x) > self.L, "The first sequence will be thrown away"
         self._one_channel(x)
         plan, iir = self._plan(), self._iir('d')
         x2, code, n_rows, n_ch, rs, cs = Plan._as_capture(x)
+        if n_rows % self.L:
+            raise ValueError("number of frames %d is not a multiple of L=%d" % (n_rows, self.L))
         d_x = DeviceBuffer(((n_rows - 1) * rs + (n_ch - 1) * cs + 1) * x2.itemsize, plan.device)
-        d_y = DeviceBuffer(n_rows * 8, plan.device)
         d_h = DeviceBuffer(self.L * plan.np_dtype().itemsize, plan.device)
         try:
             _L.check(_L.lib().zmls_dev_upload(plan.device, d_x.ptr, x2.ctypes.data, d_x.nbytes))
-            iir.reserve(n_rows, 1)
-            plan.reserve(1, staging=True)
-            iir.filter_device(d_x.ptr, code, n_rows, 1, rs, cs, d_y.ptr, 1, 1)
-            plan.impulse_device(d_y.ptr, _L.ZMLS_F64, n_rows, 1, 1, 1, d_h.ptr, 1, 1)
+            iir.reserve_fused(plan, n_rows, 1)
+            plan.impulse_filtered_device(iir, d_x.ptr, code, n_rows, 1, rs, cs, d_h.ptr, 1, 1)
             sync(plan.device)
             imp = d_h.download((self.L, 1), plan.np_dtype).astype(np.float64, copy=False)
         finally:
             d_x.free()
-            d_y.free()
             d_h.free()
         return Audio(fs=self.fs, initialdata=imp)
+
+    def get_impulses_deemphasised(self, x):
+        """Additive, many channels at once: x (R*L, C) -> (L, C), every column as MLS_simple.get_impulse treats its
+        input (de-emphasis, then the impulse response), in one device call."""
+        assert isinstance(x, np.ndarray) and x.ndim == 2
+        assert len(x) > self.L, "The first sequence will be thrown away"
+        if len(x) % self.L:
+            raise ValueError("number of frames %d is not a multiple of L=%d" % (len(x), self.L))
+        plan, iir = self._plan(), self._iir('d')
+        x2, code, n_rows, n_ch, rs, cs = Plan._as_capture(x)
+        es = plan.np_dtype().itemsize
+        d_x = DeviceBuffer(((n_rows - 1) * rs + (n_ch - 1) * cs + 1) * x2.itemsize, plan.device)
+        d_h = DeviceBuffer(self.L * n_ch * es, plan.device)
+        try:
+            _L.check(_L.lib().zmls_dev_upload(plan.device, d_x.ptr, x2.ctypes.data, d_x.nbytes))
+            iir.reserve_fused(plan, n_rows, n_ch)
+            plan.impulse_filtered_device(iir, d_x.ptr, code, n_rows, n_ch, rs, cs, d_h.ptr, n_ch, 1)
+            sync(plan.device)
+            return d_h.download((self.L, n_ch), plan.np_dtype).astype(np.float64, copy=False)
+        finally:
+            d_x.free()
+            d_h.free()
 
     def get_impulse(self, x):
         """Impulse response as an `Audio` (mls.py:409-414)."""
