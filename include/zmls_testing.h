@@ -86,6 +86,15 @@ int zmls_host_geometry_selfcheck(int K, int tile_cfg, int first_pass);
  * allocated at the end [7] most buffers allocated at once. */
 int zmls_host_placement_sim(const float *ms_of_alloc, int n_ms, int max_live, int tries, float model_ms, int64_t out[8]);
 
+/* ---- loopback transport for the period-sharded entry points: P "ranks" that are THREADS of one process on one GPU
+ * (own plan, communicator and stream each). RCCL refuses two ranks on one device, and a test box has one GPU: this is
+ * how zmls_impulse_period_sharded_device runs with P > 1 there. The exchange keeps a collective's stream semantics
+ * (comm.hip); every rank must call from its own thread with its own non-null stream, like ranks of a real job.
+ * A hub holds 1..16 ranks; destroy the communicators before the hub. */
+int zmls_comm_loopback_hub_create(void **hub, int n_ranks);
+int zmls_comm_loopback_hub_destroy(void *hub);
+int zmls_comm_create_loopback(zmls_comm **out, void *hub, int rank, int device);
+
 /* ---- what this GPU streams, measured in the same run as the benchmark (bench.py's roofline calibration): hand-written
  * 16-byte-per-lane kernels over `bytes` bytes at d_buf (a multiple of 4096; the buffer's contents are destroyed by mode 1).
  * mode 0: read only (every lane adds up what it loads; nothing is written). mode 1: copy of the first half onto the

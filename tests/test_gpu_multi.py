@@ -92,6 +92,70 @@ def test_period_sums_in_the_exchange_layout_chunk_by_chunk(P, chunk):
     d_x.free()
 
 
+@pytest.mark.parametrize("P,N,C,R,chunk,dtype", [(2, 12, 48, 5, 8, "f64"), (4, 14, 64, 9, 16, "f64"), (8, 10, 64, 3, 3, "f64"), (3, 13, 48, 7, 16, "f32"),
+                                                  (4, 16, 128, 4, 8, "f64")])
+def test_fused_entry_point_on_several_ranks_through_the_loopback_transport(P, N, C, R, chunk, dtype):
+    """zmls_impulse_period_sharded_device with P > 1: every rank is a thread with its own plan, communicator and stream on
+    the one GPU, the exchange is the library's loopback transport (same stream semantics as the RCCL call it stands in
+    for). Rank r holds periods r, r+P, ... (rank 0 the discarded one; with R < P some ranks hold none) and must end up
+    with channel block r of what zmls_impulse_device makes of the whole capture; also held to the oracle."""
+    import ctypes
+    import threading
+    from zignal_amd.device import Plan
+    taps = TAPS[N][0]
+    ref_plan = plan(N, taps, dtype)
+    L, npdt = ref_plan.L, ref_plan.np_dtype
+    rng = np.random.default_rng(P * 100 + N)
+    x = rng.standard_normal((R * L, C)).astype(npdt)
+    d_all, d_ref = DeviceBuffer(x.nbytes).upload(x), DeviceBuffer(L * C * x.itemsize)
+    ref_plan.reserve(C)
+    ref_plan.impulse_device(d_all.ptr, ref_plan.dtype_code, R * L, C, C, 1, d_ref.ptr, C, 1)
+    sync(0)
+    want = d_ref.download((L, C), npdt).astype(np.float64)
+    hub = multi.LoopbackHub(P)
+    share = C // P
+    results, errors = [None] * P, []
+
+    def rank_main(r):
+        try:
+            p = Plan(N, taps, dtype=dtype, device=0)
+            comm = multi.Comm.loopback(hub, r, 0)
+            stream = ctypes.c_void_p()
+            _lib.check(_lib.lib().zmls_stream_create(0, ctypes.byref(stream)))
+            mine, skip, total = multi.period_shard(R, P, r)
+            local = np.ascontiguousarray(np.concatenate([x[q * L:(q + 1) * L] for q in mine], axis=0)) if mine else np.zeros((1, C), npdt)
+            d_x = DeviceBuffer(local.nbytes).upload(local)
+            d_h = DeviceBuffer(L * share * x.itemsize)
+            d_h.fill(0xFF)
+            ps = multi.PeriodSharded(p, comm, chunk)
+            for _ in range(2):                        # twice in a row on the same staging buffers
+                ps.impulse_device(d_x.ptr, p.dtype_code, len(mine) * L, skip, total, C, C, 1, d_h.ptr, share, 1, stream=stream)
+            _lib.check(_lib.lib().zmls_stream_sync(0, stream))
+            results[r] = d_h.download((L, share), npdt).astype(np.float64)
+            _lib.check(_lib.lib().zmls_stream_destroy(0, stream))
+            comm.close()
+            p.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck"
+    assert not errors, errors
+    hub.close()
+    got = np.concatenate(results, axis=1)
+    peak = np.max(np.abs(want))
+    # same samples added up in another order (partial sums per rank, then across ranks): equal to rounding
+    assert np.max(np.abs(got - want)) <= (1e-14 if dtype == "f64" else 2e-6) * peak
+    ora = _oracle_all(N, taps, x[:, ::max(1, C // 4)])
+    assert rel_err(got[:, ::max(1, C // 4)], ora) <= (1e-12 if dtype == "f64" else 1e-5)
+    d_all.free()
+    d_ref.free()
+
+
 def test_two_ranks_on_two_gpus_over_rccl():
     """The fused period-sharded entry point with a real two-rank communicator: needs two GPUs (the driver's multi-GPU
     node; a one-GPU test box skips it - RCCL refuses two ranks on one device). Each rank is a process of its own

@@ -51,6 +51,9 @@ SIGNATURES = {
     "zmls_comm_unique_id": [c_vp],
     "zmls_comm_create": [_vpp, c_vp, c_int, c_int, c_int],
     "zmls_comm_destroy": [c_vp],
+    "zmls_comm_loopback_hub_create": [_vpp, c_int],
+    "zmls_comm_loopback_hub_destroy": [c_vp],
+    "zmls_comm_create_loopback": [_vpp, c_vp, c_int, c_int],
     "zmls_comm_info": [c_vp, ctypes.POINTER(c_i64)],
     "zmls_comm_reserve": [c_vp, c_vp, c_i64],
     "zmls_comm_reduce_scatter_device": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],

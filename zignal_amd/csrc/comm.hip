@@ -15,6 +15,9 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <rccl/rccl.h>
 #include "zmls_internal.h"
 
@@ -69,6 +72,57 @@ Rccl *rccl()
 ncclDataType_t nccl_type(int dtype) { return dtype == ZMLS_F64 ? ncclFloat64 : ncclFloat32; }
 
 } // namespace
+
+// ---- loopback transport (tests only, zmls_testing.h): P "ranks" that are threads of ONE process on ONE GPU, each with
+// its own plan, communicator and streams. A test box has a single GPU and RCCL refuses two ranks on one device, so this
+// is how the P > 1 side of zmls_impulse_period_sharded_device - block layout of the exchange, chunking, buffer reuse,
+// event order - runs at all there. The collective keeps RCCL's stream semantics: it is enqueued on the rank's stream,
+// reads every rank's send buffer once all of them have produced it, and is complete on a rank only when all ranks
+// have finished reading that rank's send buffer.
+constexpr int kMaxLoopRanks = 16;
+struct LoopHub {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;
+    const void *send[kMaxLoopRanks] = {};
+    hipEvent_t ready[kMaxLoopRanks] = {}, done[kMaxLoopRanks] = {};
+};
+
+namespace {
+
+// all ranks meet here on the host; false if one of them does not show up (the test then fails instead of hanging)
+bool hub_barrier(LoopHub *h)
+{
+    std::unique_lock<std::mutex> lk(h->mu);
+    if (h->broken) return false;
+    const uint64_t gen = h->generation;
+    if (++h->arrived == h->n) {
+        h->arrived = 0;
+        ++h->generation;
+        h->cv.notify_all();
+        return true;
+    }
+    if (!h->cv.wait_for(lk, std::chrono::seconds(30), [&] { return h->generation != gen || h->broken; })) h->broken = true;
+    if (h->broken) { h->cv.notify_all(); return false; }
+    return true;
+}
+
+struct LoopPeers { const void *send[kMaxLoopRanks]; };      // by value in the kernel arguments: fixed at launch
+
+template <typename T>
+__global__ void __launch_bounds__(256) loop_reduce_kernel(const LoopPeers peers, int n, uint64_t first, uint64_t count, T *__restrict__ recv)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        T s = ((const T *)peers.send[0])[first + i];
+        for (int q = 1; q < n; ++q) s += ((const T *)peers.send[q])[first + i];      // rank order, as a ring sum would not be: equal to rounding
+        recv[i] = s;
+    }
+}
+
+} // namespace
 } // namespace zmls
 
 struct zmls_comm {
@@ -81,6 +135,9 @@ struct zmls_comm {
     int64_t chunk_ch;           // channels of one rank's share that go through the exchange at a time
     int staging_dtype;
     int64_t staging_L;
+    // loopback transport (tests): null for RCCL
+    zmls::LoopHub *hub;
+    hipEvent_t loop_ready, loop_done;
 };
 
 using namespace zmls;
@@ -96,7 +153,82 @@ static void free_staging(zmls_comm *c)
     c->chunk_ch = 0;
 }
 
+// the one exchange of the path: recv[i] = sum over ranks of their send[rank * recv_count + i], on stream cs
+static int reduce_scatter(zmls_comm *c, const void *send, void *recv, size_t recv_count, int dtype, hipStream_t cs)
+{
+    if (!c->hub) {
+        Rccl *R = rccl();
+        if (!R) return ZMLS_E_COMM;
+        ZNCCL(R, R->ReduceScatter(send, recv, recv_count, nccl_type(dtype), ncclSum, c->nccl, cs));
+        return ZMLS_OK;
+    }
+    LoopHub *h = c->hub;
+    ZHIP(hipEventRecord(c->loop_ready, cs));                   // my send buffer is complete at this point of my stream
+    h->send[c->rank] = send;
+    h->ready[c->rank] = c->loop_ready;
+    if (!hub_barrier(h)) { set_error("loopback exchange: a rank did not arrive"); return ZMLS_E_COMM; }
+    LoopPeers peers;
+    memset(&peers, 0, sizeof peers);
+    for (int q = 0; q < h->n; ++q) {
+        peers.send[q] = h->send[q];
+        ZHIP(hipStreamWaitEvent(cs, h->ready[q], 0));
+    }
+    const uint32_t grid = (uint32_t)((recv_count + 255) / 256 > 4096 ? 4096 : (recv_count + 255) / 256);
+    if (dtype == ZMLS_F64)
+        hipLaunchKernelGGL(loop_reduce_kernel<double>, dim3(grid), dim3(256), 0, cs, peers, h->n, (uint64_t)c->rank * recv_count, (uint64_t)recv_count, (double *)recv);
+    else
+        hipLaunchKernelGGL(loop_reduce_kernel<float>, dim3(grid), dim3(256), 0, cs, peers, h->n, (uint64_t)c->rank * recv_count, (uint64_t)recv_count, (float *)recv);
+    ZHIP(hipGetLastError());
+    ZHIP(hipEventRecord(c->loop_done, cs));
+    h->done[c->rank] = c->loop_done;
+    if (!hub_barrier(h)) { set_error("loopback exchange: a rank did not arrive"); return ZMLS_E_COMM; }
+    for (int q = 0; q < h->n; ++q) ZHIP(hipStreamWaitEvent(cs, h->done[q], 0));      // complete here only when nobody reads my send buffer any more
+    if (!hub_barrier(h)) { set_error("loopback exchange: a rank did not arrive"); return ZMLS_E_COMM; }     // nobody re-publishes before all have read the hub
+    return ZMLS_OK;
+}
+
 extern "C" {
+
+int zmls_comm_loopback_hub_create(void **hub, int n_ranks)
+{
+    if (!hub || n_ranks < 1 || n_ranks > kMaxLoopRanks) { set_error("loopback hubs hold 1..%d ranks", kMaxLoopRanks); return ZMLS_E_ARG; }
+    LoopHub *h = new LoopHub;
+    h->n = n_ranks;
+    *hub = h;
+    return ZMLS_OK;
+}
+
+int zmls_comm_loopback_hub_destroy(void *hub)
+{
+    delete (LoopHub *)hub;
+    return ZMLS_OK;
+}
+
+int zmls_comm_create_loopback(zmls_comm **out, void *hub, int rank, int device)
+{
+    if (!out || !hub) { set_error("null argument"); return ZMLS_E_ARG; }
+    *out = nullptr;
+    LoopHub *h = (LoopHub *)hub;
+    if (rank < 0 || rank >= h->n) { set_error("rank %d outside 0..%d", rank, h->n - 1); return ZMLS_E_ARG; }
+    ZDEVICE(device);
+    zmls_comm *c = (zmls_comm *)calloc(1, sizeof(zmls_comm));
+    if (!c) { set_error("out of host memory"); return ZMLS_E_ARG; }
+    c->rank = rank; c->n_ranks = h->n; c->device = device; c->hub = h;
+    hipError_t e = hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&c->e_sum[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->e_rs[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->loop_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->loop_done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        const int rc = hip_fail(e, "loopback communicator");
+        (void)zmls_comm_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return ZMLS_OK;
+}
 
 int zmls_comm_unique_id(uint8_t *id)
 {
@@ -156,9 +288,13 @@ int zmls_comm_destroy(zmls_comm *c)
             if (c->e_rs[i]) (void)hipEventDestroy(c->e_rs[i]);
         }
         if (c->cs) (void)hipStreamDestroy(c->cs);
+        if (c->loop_ready) (void)hipEventDestroy(c->loop_ready);
+        if (c->loop_done) (void)hipEventDestroy(c->loop_done);
     }
-    Rccl *R = rccl();
-    if (R && c->nccl) (void)R->CommDestroy(c->nccl);
+    if (!c->hub) {
+        Rccl *R = rccl();
+        if (R && c->nccl) (void)R->CommDestroy(c->nccl);
+    }
     free(c);
     return ZMLS_OK;
 }
@@ -202,17 +338,14 @@ int zmls_comm_reduce_scatter_device(zmls_comm *c, const void *d_send, void *d_re
     if (!c || !d_send || !d_recv || recv_count < 1) { set_error("bad reduce_scatter arguments"); return ZMLS_E_ARG; }
     if (dtype != ZMLS_F64 && dtype != ZMLS_F32) { set_error("reduce_scatter moves f64 or f32"); return ZMLS_E_ARG; }
     ZDEVICE(c->device);
-    int rc = ZMLS_OK;
-    Rccl *R = rccl();
-    if (!R) return ZMLS_E_COMM;
-    ZNCCL(R, R->ReduceScatter(d_send, d_recv, (size_t)recv_count, nccl_type(dtype), ncclSum, c->nccl, (hipStream_t)stream));
-    return ZMLS_OK;
+    return reduce_scatter(c, d_send, d_recv, (size_t)recv_count, dtype, (hipStream_t)stream);
 }
 
 int zmls_comm_all_gather_device(zmls_comm *c, const void *d_send, void *d_recv, int64_t send_count, int dtype, void *stream)
 {
     if (!c || !d_send || !d_recv || send_count < 1) { set_error("bad all_gather arguments"); return ZMLS_E_ARG; }
     if (dtype != ZMLS_F64 && dtype != ZMLS_F32) { set_error("all_gather moves f64 or f32"); return ZMLS_E_ARG; }
+    if (c->hub) { set_error("the loopback transport has the reduce-scatter only"); return ZMLS_E_UNSUPPORTED; }
     ZDEVICE(c->device);
     int rc = ZMLS_OK;
     Rccl *R = rccl();
@@ -265,8 +398,6 @@ int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d
     if (c->chunk_ch < 1 || c->staging_dtype != p->dtype || c->staging_L != p->L) { set_error("call zmls_comm_reserve(comm, plan, chunk_channels) first"); return ZMLS_E_WORKSPACE; }
     ZDEVICE(c->device);
     int rc = ZMLS_OK;
-    Rccl *R = rccl();
-    if (!R) return ZMLS_E_COMM;
     hipStream_t st = (hipStream_t)stream;
     const size_t ts = dtype_size(p->dtype);
     const int64_t share = n_ch / c->n_ranks;                 // channels this rank ends up with
@@ -283,7 +414,8 @@ int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d
         }
         ZHIP(hipEventRecord(c->e_sum[buf], st));
         ZHIP(hipStreamWaitEvent(c->cs, c->e_sum[buf], 0));
-        ZNCCL(R, R->ReduceScatter(c->d_send[buf], c->d_recv[buf], (size_t)(p->L * cc), nccl_type(p->dtype), ncclSum, c->nccl, c->cs));
+        const int rs = reduce_scatter(c, c->d_send[buf], c->d_recv[buf], (size_t)(p->L * cc), p->dtype, c->cs);
+        if (rs) return rs;
         ZHIP(hipEventRecord(c->e_rs[buf], c->cs));
         return ZMLS_OK;
     };

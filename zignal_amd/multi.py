@@ -115,6 +115,16 @@ class Comm:
         L.check(L.lib().zmls_comm_create(ctypes.byref(h), buf, self.rank, self.world, self.device))
         self._h = h
 
+    @classmethod
+    def loopback(cls, hub, rank, device=0):
+        """This rank's end of a loopback exchange among threads of one process on one GPU (tests: zmls_testing.h)."""
+        self = cls.__new__(cls)
+        self.rank, self.world, self.device = int(rank), hub.world, int(device)
+        h = ctypes.c_void_p()
+        L.check(L.lib().zmls_comm_create_loopback(ctypes.byref(h), hub._h, self.rank, self.device))
+        self._h = h
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             L.lib().zmls_comm_destroy(self._h)
@@ -140,6 +150,21 @@ class Comm:
 
     def all_gather_device(self, d_send, d_recv, send_count, dtype_code, stream=None):
         L.check(L.lib().zmls_comm_all_gather_device(self._h, d_send, d_recv, int(send_count), dtype_code, stream))
+
+
+class LoopbackHub:
+    """Meeting point of the `world` virtual ranks of a loopback exchange (tests only)."""
+
+    def __init__(self, world):
+        self.world = int(world)
+        h = ctypes.c_void_p()
+        L.check(L.lib().zmls_comm_loopback_hub_create(ctypes.byref(h), self.world))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().zmls_comm_loopback_hub_destroy(self._h)
+            self._h = None
 
 
 class PeriodSharded:
