@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                  on a bounded sample of the same workload
   configs      : (N=1, default workload) the other BASELINE.json configurations that fit one GPU, a few
                  steps each with their own roofline, parity against the oracle and CPU baseline
+  order_sweep  : (with configs) N = 16..24 on the same 10.7 GB of capture each (2^(28-N) channels x 4 averaged periods)
   period_mode  : (N>1) the same batch with the PERIODS striped over the GPUs instead of the channels:
                  partial period sums reduce-scattered with RCCL over xGMI (BASELINE config 3's
                  "RCCL reduce"); `value` stays the channel-sharded (collective-free) number.
@@ -361,6 +362,39 @@ def run_extra_config(spec, dev, cpu_seconds, keep):
     return out
 
 
+def order_sweep(dev):
+    """north_star: 'throughput is measured on synthetic captures, MLS orders N=16-24': one entry per order, the same
+    10.7 GB of capture each (2^(28-N) channels x 5 periods, 4 averaged, f64, frame-major), device time of 5 steps."""
+    out = []
+    for N in range(16, 25):
+        C, Ravg = 1 << (28 - N), 4
+        R = Ravg + 1
+        plan = Plan(N, TAPS[N][0], dtype="f64", device=dev)
+        L = plan.L
+        plan.reserve(C)
+        d_x, d_h = DeviceBuffer(R * L * C * 8, dev), DeviceBuffer(L * C * 8, dev)
+        plan.synth_device(d_x.ptr, _lib.ZMLS_F64, R, C, C, 1, seed=SEED, sigma=1e-3)
+        for _ in range(2):
+            plan.impulse_device(d_x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, d_h.ptr, C, 1)
+        sync(dev)
+        tm = Timer(dev)
+        tm.start()
+        for _ in range(5):
+            plan.impulse_device(d_x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, d_h.ptr, C, 1)
+        tm.stop()
+        ms = tm.elapsed_ms() / 5
+        alg = (Ravg + 1) * L * 8 * C
+        info = plan.info()
+        passes = info["tall_passes"] or info["passes"]
+        out.append({"order": N, "channels": C, "averaged_periods": Ravg, "passes": passes, "ms_per_step": ms,
+                    "value": C * Ravg * L / (ms * 1e-3) / 1e9, "achieved_GBps": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "system_check_max_abs_err": system_check(plan, d_h, _lib.ZMLS_F64, C, C, 1, SEED, 0)})
+        d_x.free()
+        d_h.free()
+        plan.close()
+    return out
+
+
 # --------------------------------------------------------------------------------------------- the RCCL leg
 def period_leg(args, world, rank, dev, dist, plan, dtype_code, es, C, R, result):
     """The same batch with the periods, not the channels, spread over the ranks (second mode): rank r
@@ -650,6 +684,10 @@ def main():
             except Exception as e:  # noqa: BLE001  (the headline must survive a failure here; the entry says what happened)
                 extra.append({"baseline_config": spec[1], "error": "%s: %s" % (type(e).__name__, e)})
         out["configs"] = extra
+        try:
+            out["order_sweep"] = order_sweep(dev)
+        except Exception as e:  # noqa: BLE001
+            out["order_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
         bad = [c.get("workload", c["baseline_config"]) for c in extra if "error" in c
                or (c.get("parity_max_rel_err_vs_oracle") or 0) > TOL[c["dtype"]]
                or c["system_check_max_abs_err"] > noise_tolerance(c["averaged_periods"], (1 << c["order"]) - 1)]
