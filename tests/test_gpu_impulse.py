@@ -459,3 +459,17 @@ def test_single_pass_orders_in_the_register_tile(N, dtype):
         assert np.array_equal(p.impulse_host(x), h_auto)
         p.force_tile(-1)
         assert rel_err(h_auto[:, :64], h_small.astype(np.float64)) <= tol_pair
+
+
+def test_capture_alloc_stats_and_free_through_the_c_abi():
+    """small captures are simply allocated (nothing to choose: zero candidates rated); zmls_capture_free gives the buffer back"""
+    import ctypes
+    p = plan(12, TAPS[12][0])
+    lib = _lib.lib()
+    ptr, stats = ctypes.c_void_p(), (ctypes.c_float * 8)()
+    assert lib.zmls_capture_alloc_stats(p._h, _lib.ZMLS_F64, 3 * p.L, 8, 0, ctypes.byref(ptr), stats) == 0 and ptr.value
+    assert list(stats)[:3] == [0.0, 0.0, 0.0]
+    assert lib.zmls_dev_memset(0, ptr, 0, 3 * p.L * 8 * 8) == 0
+    assert lib.zmls_capture_free(p._h, ptr) == 0
+    assert lib.zmls_capture_free(p._h, None) == 0 and lib.zmls_capture_free(None, None) == _lib.E_ARG
+    assert lib.zmls_capture_alloc_stats(p._h, _lib.ZMLS_F64, p.L, 8, 0, ctypes.byref(ptr), stats) == _lib.E_ARG      # one period: nothing to average
