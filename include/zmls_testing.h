@@ -69,6 +69,10 @@ int zmls_dev_download_channel(int device, void *dst, const void *d_src, int dtyp
  * Ps / Pl as defined in SURVEY.md §A.2. */
 int zmls_plan_export_table(zmls_plan *p, int which, uint32_t *out);
 
+/* tuning: overwrite the gather table (which = 0) with 2^N entries of the caller's, e.g. a sorted one, to time the gather
+ * pass on rows that are not scattered (tools/gather_order.py). The plan's responses are meaningless afterwards. */
+int zmls_plan_import_table(zmls_plan *p, int which, const uint32_t *in);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU test tier) */
 /* how a 2^N-point transform is split into LDS-resident passes: bits[i] for i < returned count */
 int zmls_host_pass_split(int N, int bits[4]);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "zmls_event_elapsed_ms": [c_int, c_vp, c_vp, ctypes.POINTER(ctypes.c_float)],
     "zmls_dev_download_channel": [c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64],
     "zmls_plan_export_table": [c_vp, c_int, c_vp],
+    "zmls_plan_import_table": [c_vp, c_int, c_vp],
     "zmls_host_pass_split": [c_int, ctypes.POINTER(c_int)],
     "zmls_host_lfsr_state": [c_int, _i32p, c_int, c_u64, ctypes.POINTER(ctypes.c_uint32)],
     "zmls_host_geometry_selfcheck": [c_int, c_int, c_int],

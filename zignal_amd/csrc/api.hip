@@ -837,6 +837,17 @@ int zmls_plan_export_table(zmls_plan *p, int which, uint32_t *out)
     return ZMLS_OK;
 }
 
+// tuning only: replace the gather table (which = 0) by the caller's, e.g. a sorted one, to time the gather pass on
+// rows that are not scattered; the responses are then meaningless
+int zmls_plan_import_table(zmls_plan *p, int which, const uint32_t *in)
+{
+    if (!p || !in || which != 0) { set_error("bad import arguments"); return ZMLS_E_ARG; }
+    if (int rc0 = sequence_only(p)) return rc0;
+    ZDEVICE(p->device);
+    ZHIP(hipMemcpy(p->d_gather, in, ((size_t)1 << p->N) * 4, hipMemcpyHostToDevice));
+    return ZMLS_OK;
+}
+
 // ---- thin HIP wrappers for ctypes callers ---------------------------------------------------
 int zmls_dev_alloc(int device, void **d_ptr, size_t bytes)
 {
