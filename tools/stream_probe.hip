@@ -91,6 +91,28 @@ int main(int argc, char **argv)
         printf("blocked copy, grid %6d (%.1f MiB per workgroup): u4 %.0f  u8 %.0f\n", grid, per * 16 / 1048576.0,
                2 * bytes / 1e6 / timeit([&] { cp_blocked<4><<<grid, 256>>>(a, b, per); }), 2 * bytes / 1e6 / timeit([&] { cp_blocked<8><<<grid, 256>>>(a, b, per); }));
     }
+    // Does the Infinity Cache (256 MiB) serve lines back that a kernel has just WRITTEN? write S bytes, then read them,
+    // for S inside and beyond the cache; beside it, the read of S bytes that were read just before (warm) and of S cold bytes
+    for (size_t mb : {32, 64, 128, 192, 384, 1024}) {
+        const size_t sb = mb << 20, sn = sb / 16;
+        float t_rw = 1e30f, t_rr = 1e30f, t_cold = 1e30f, t_w = 1e30f;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int r = 0; r < 5; ++r) {
+            float ms;
+            // flush: sweep 2 GiB of the other buffer
+            rd<8, false><<<4096, 256>>>(a, (size_t)(2048u << 20) / 16 * 1, (uint32_t *)a);
+            CK(hipEventRecord(e0)); wr<false><<<4096, 256>>>(b, sn); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < t_w) t_w = ms;
+            CK(hipEventRecord(e0)); rd<1, false><<<2048, 256>>>(b, sn, (uint32_t *)a); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < t_rw) t_rw = ms;
+            CK(hipEventRecord(e0)); rd<1, false><<<2048, 256>>>(b, sn, (uint32_t *)a); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < t_rr) t_rr = ms;
+            rd<8, false><<<4096, 256>>>(a, (size_t)(2048u << 20) / 16 * 1, (uint32_t *)a);
+            CK(hipEventRecord(e0)); rd<1, false><<<2048, 256>>>(b, sn, (uint32_t *)a); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < t_cold) t_cold = ms;
+        }
+        printf("%5zu MiB: write %.0f GB/s | read after write %.0f | read after read %.0f | read cold %.0f\n", mb, sb / 1e6 / t_w, sb / 1e6 / t_rw, sb / 1e6 / t_rr, sb / 1e6 / t_cold);
+    }
     printf("hipMemcpyDtoD (r+w) %.0f\n", 2 * bytes / 1e6 / timeit([&] { CK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0)); }));
     return 0;
 }
