@@ -337,13 +337,39 @@ int launch_iir_cc(bool time_contiguous, const IirDev *d_f, const void *d_x, int 
 // covers frames [L - (n_chunks - q) TT, L - (n_chunks - q - 1) TT); the first one starts before the period does and
 // reads zeros there, which leaves a filter at rest at rest - so every end state is exact and every chunk boundary is
 // one A^TT away from the next.
+// zero-state end state of the chunk in `tile` (run-major, as iir_chunk_kernel lays it out): every thread runs its 32-frame
+// run from rest, then the in-LDS scan with A^32, A^64, ...; the threads of the last run hold the chunk's end state in z
+template <int S, int CC>
+__device__ __forceinline__ void chunk_end_state(const IirDev *__restrict__ f, const double *tile, double *sc, int tid, double (&z)[S])
+{
+    constexpr int LOGNB = (CC == 1) ? 8 : 4;
+    const int sb = tid / CC;
+#pragma unroll
+    for (int k = 0; k < S; ++k) z[k] = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < kIirSub; ++i) (void)df2t_step<S>(f, tile[tid * kIirPitch + i], z);
+#pragma unroll
+    for (int d = 0; d < LOGNB; ++d) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) sc[tid * S + k] = z[k];
+        __syncthreads();
+        if (sb >= (1 << d)) {
+            double u[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) u[k] = sc[(tid - (CC << d)) * S + k];
+            matvec_acc<S>(f->P[d], u, z);
+        }
+        __syncthreads();
+    }
+}
+
 template <int S, int CC>
 __global__ void __launch_bounds__(256, (S <= 5 ? 2 : 1)) iir_period_kernel(const IirDev *__restrict__ f, const void *__restrict__ x, int in_dtype, int64_t L, int R,
                                                          int64_t n_ch, int64_t rs, int64_t cs, uint32_t n_cgrp, int64_t n_chunks,
-                                                         double *__restrict__ e, double *__restrict__ sum, int64_t srs, int64_t scs)
+                                                         double *__restrict__ e, double *__restrict__ sum, int64_t srs, int64_t scs,
+                                                         int vec /* 16-byte accesses are aligned on both sides (frame-major tiles only) */)
 {
     constexpr int NB = 256 / CC;
-    constexpr int LOGNB = (CC == 1) ? 8 : 4;
     constexpr int TT = NB * kIirSub;
     constexpr int PER = TT * CC / 256;
     __shared__ double tile[256 * kIirPitch];
@@ -354,6 +380,48 @@ __global__ void __launch_bounds__(256, (S <= 5 ? 2 : 1)) iir_period_kernel(const
     const bool interior = in_dtype == ZMLS_F64 && j0 >= 0 && c0 + CC <= n_ch;
     const int sb = tid / CC;
     const int64_t c = c0 + tid % CC;
+    double z[S];
+
+    if constexpr (CC == 16) {
+        if (vec && interior) {
+            // interior tiles of aligned float64 frames: 16 loads of 16 bytes (two adjacent channels) in flight per lane.
+            // Vector i of this thread is frame tid/8 + 32 i of the tile, channels 2 (tid%8) and 2 (tid%8) + 1: run i, offset tid/8.
+            typedef double D2 __attribute__((ext_vector_type(2)));
+            constexpr int NV = PER / 2;
+            const int fr = tid >> 3, cp = (tid & 7) * 2;
+            const int64_t vstep = 32 * rs;
+            D2 acc2[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) acc2[i] = (D2)0.0;
+            for (int r = 0; r < R; ++r) {
+                const double *q = (const double *)x + ((int64_t)r * L + j0 + fr) * rs + c0 + cp;
+                D2 v2[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i, q += vstep) v2[i] = __builtin_nontemporal_load((const D2 *)q);
+                if (r >= 1) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) acc2[i] += v2[i];       // period order, as numpy adds the rows (mls.py:298-306)
+                }
+                if (r + 1 == R) break;                                   // the last period rings into nothing that is kept
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    tile[(i * CC + cp) * kIirPitch + fr] = v2[i][0];
+                    tile[(i * CC + cp + 1) * kIirPitch + fr] = v2[i][1];
+                }
+                __syncthreads();
+                chunk_end_state<S, CC>(f, tile, sc, tid, z);
+                if (sb == NB - 1) {
+#pragma unroll
+                    for (int k = 0; k < S; ++k) e[(((int64_t)r * n_chunks + chunk) * n_ch + c) * S + k] = z[k];
+                }
+            }
+            double *o = sum + (j0 + fr) * srs + c0 + cp;
+#pragma unroll
+            for (int i = 0; i < NV; ++i, o += 32 * srs) *(D2 *)o = acc2[i];
+            return;
+        }
+    }
+
     // element i of this thread in the coalesced sweeps: frame tt0 + i * FSTEP of the tile, channel cc0
     constexpr int FSTEP = 256 / CC;
     constexpr int HALF = PER / 2;                       // loads in flight per lane (two halves keep the kernel at two workgroups per CU)
@@ -392,24 +460,7 @@ __global__ void __launch_bounds__(256, (S <= 5 ? 2 : 1)) iir_period_kernel(const
         }
         if (!keep_state) break;
         __syncthreads();
-        double z[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) z[k] = 0.0;
-#pragma unroll 4
-        for (int i = 0; i < kIirSub; ++i) (void)df2t_step<S>(f, tile[tid * kIirPitch + i], z);
-#pragma unroll
-        for (int d = 0; d < LOGNB; ++d) {
-#pragma unroll
-            for (int k = 0; k < S; ++k) sc[tid * S + k] = z[k];
-            __syncthreads();
-            if (sb >= (1 << d)) {
-                double u[S];
-#pragma unroll
-                for (int k = 0; k < S; ++k) u[k] = sc[(tid - (CC << d)) * S + k];
-                matvec_acc<S>(f->P[d], u, z);
-            }
-            __syncthreads();
-        }
+        chunk_end_state<S, CC>(f, tile, sc, tid, z);
         if (sb == NB - 1 && c < n_ch) {
 #pragma unroll
             for (int k = 0; k < S; ++k) e[(((int64_t)r * n_chunks + chunk) * n_ch + c) * S + k] = z[k];
@@ -485,7 +536,8 @@ int launch_period_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t L,
     const uint64_t blocks = n_cgrp * n_chunks, n_rc = (uint64_t)(R - 1) * (uint64_t)n_ch;
     if (blocks == 0 || blocks > 0x7FFFFFFFull || n_rc > 0x7FFFFFFFull * 64) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
     hipLaunchKernelGGL((iir_period_kernel<S, CC>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, L, (int)R, n_ch, rs, cs, (uint32_t)n_cgrp,
-                       (int64_t)n_chunks, d_e, d_sum, srs, scs);
+                       (int64_t)n_chunks, d_e, d_sum, srs, scs,
+                       (CC == 16 && cs == 1 && scs == 1 && rs % 2 == 0 && srs % 2 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_sum & 15) == 0) ? 1 : 0);
     hipLaunchKernelGGL(iir_period_end_kernel<S>, dim3((uint32_t)((n_rc + 63) / 64)), dim3(64), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch, (int64_t)n_rc,
                        (const double *)d_e, d_E);
     hipLaunchKernelGGL(iir_period_chain_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_phi, (int)R, n_ch, (const double *)d_E, d_zi);
