@@ -42,7 +42,7 @@ def test_audio_fft_against_reference_spectra():
         check(mag, arrays[c["id"] + "_mag"])
 
 
-@pytest.mark.parametrize("N,ch", [(16, 1), (17, 2), (19, 1), (20, 1), (18, 5)])
+@pytest.mark.parametrize("N,ch", [(16, 1), (17, 2), (19, 1), (20, 1), (18, 5), (16, 4), (14, 3), (20, 2)])   # odd sizes with >= 2 channels: two channels per complex transform
 def test_mls_sized_responses_against_the_oracle(N, ch):
     """L = 2^N - 1 points (odd, composite or Mersenne prime: N = 17, 19 get the size bump), rectangular window,
     not normalised: exactly what MLS_simple.plot_fft asks for (mls.py:466)."""
