@@ -281,6 +281,23 @@ def dump_api():
     write_json("api.json", meta)
 
 
+def dump_simple_short():
+    """MLS_simple.get_impulse (de-emphasis + impulse response, mls.py:454-458) at orders whose period is far shorter
+    than the emphasis filter's memory (100 Hz shelf at 48 kHz: thousands of samples against L = 31 ... 1023), on
+    noisy, scaled captures: the period the average drops still rings into the ones it keeps."""
+    arrays, cases = {}, []
+    for cid, (N, rep, seed) in enumerate([(5, 4, 11), (6, 2, 12), (7, 3, 13), (8, 9, 14), (10, 6, 15)]):
+        ms = MLS_simple(N=N, fs=48000, repeats=rep)
+        rng = np.random.default_rng(seed)
+        x = 0.7 * np.roll(ms.samples, 3, axis=0) + 0.05 * rng.standard_normal(ms.samples.shape)
+        ir = ms.get_impulse(x)
+        key = "s%d" % cid
+        arrays[key + "_x"], arrays[key + "_ir"] = x, ir.samples.copy()
+        cases.append({"id": key, "N": N, "repeats": rep, "fs": 48000, "seed": seed, "x_sha256": inputs.digest(x)})
+    np.savez_compressed(os.path.join(HERE, "simple_short.npz"), **arrays)
+    write_json("simple_short.json", {"cases": cases})
+
+
 def dump_fft():
     """Audio.fft (audio.py:678-704) on decaying-noise 'impulse responses': an ordinary size, a Mersenne-prime size
     (fftsize bumped by one), the MLS use (rectangular, not normalised) and the default (hann, normalised)."""
@@ -307,7 +324,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     steps = {"taps": dump_taps, "errors": dump_errors, "api": dump_api, "fft": dump_fft,
-             "seq": lambda: dump_seq_kats(a.quick), "prefix": dump_seq_prefix, "ir": lambda: dump_ir(a.quick)}
+             "seq": lambda: dump_seq_kats(a.quick), "prefix": dump_seq_prefix, "simple_short": dump_simple_short, "ir": lambda: dump_ir(a.quick)}
     for name, fn in steps.items():
         if a.only and name not in a.only.split(","):
             continue

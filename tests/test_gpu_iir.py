@@ -217,3 +217,19 @@ def test_mls_get_impulses_deemphasised_many_channels():
     got = m.get_impulses_deemphasised(x)
     assert got.shape == (m.L, C) and got.dtype == np.float64
     assert rel_err(got, _reference_chain(N, TAPS[N][0], a, b, x)) <= TOL
+
+
+def test_mls_simple_short_orders_against_reference_goldens():
+    """MLS_simple.get_impulse as the REAL reference computes it (tests/golden/simple_short.*, made by make_golden.py) at
+    N = 5..10, where the emphasis filter's memory spans many periods: the fused path's summed period-boundary states."""
+    import json
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cases = json.load(open(os.path.join(G, "simple_short.json")))["cases"]
+    arrays = np.load(os.path.join(G, "simple_short.npz"))
+    for c in cases:
+        ms = MLS_simple(N=c["N"], fs=c["fs"], repeats=c["repeats"], device=0)
+        x = arrays[c["id"] + "_x"]
+        got = ms.get_impulse(x)
+        assert got.samples.shape == arrays[c["id"] + "_ir"].shape
+        assert rel_err(got.samples, arrays[c["id"] + "_ir"]) <= TOL, c

@@ -184,3 +184,21 @@ def test_audio_fft_restatement_against_reference_spectra():
         assert mag.shape == (c["bins"], c["ch"])
         assert np.array_equal(frq, arrays[c["id"] + "_frq"])
         assert np.allclose(mag, arrays[c["id"] + "_mag"], rtol=0, atol=1e-9)
+
+
+def test_oracle_chain_against_reference_mls_simple_short_orders():
+    """lfilter + the oracle's get_impulse against the real reference's MLS_simple.get_impulse at N = 5..10
+    (tests/golden/simple_short.*): pins the de-emphasis + impulse chain the GPU tests compare the fused path with."""
+    import scipy.signal
+    from zignal_amd.filters.biquads import RBJ
+    cases = load_json("simple_short.json")["cases"]
+    arrays = np.load(os.path.join(G, "simple_short.npz"))
+    from zignal_amd.measure.mlstaps import TAPS
+    for c in cases:
+        B, A = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=c["fs"]).get_coefficients()
+        x = arrays[c["id"] + "_x"]
+        assert inputs.digest(x) == c["x_sha256"]
+        y = scipy.signal.lfilter(A, B, x, axis=0)                  # de-emphasis = the inverse filter (mls.py:366)
+        h = mls_oracle.get_impulse(c["N"], TAPS[c["N"]][0], y)
+        want = arrays[c["id"] + "_ir"]
+        assert np.max(np.abs(h - want)) <= 1e-12 * np.max(np.abs(want))
