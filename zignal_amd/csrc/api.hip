@@ -748,11 +748,11 @@ int zmls_capture_alloc_stats(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t
         *ms_out = ms;
         return ZMLS_OK;
     };
-    // What the gather pass of this shape takes on a good placement: the capture read at 5.85 TB/s plus the intermediate
-    // written at 5.2 TB/s, the rates the pass reaches on MI355X (fits 12.5 ms at N=20 x 512 x 16 periods, 3.1 ms at
-    // N=20 x 1024 x 1, 12.5 ms at N=24 x 256 x 1).
+    // What the gather pass of this shape takes on a good placement: the capture read at 6.36 TB/s plus the intermediate
+    // written at 5.05 TB/s, the rates the pass (non-temporal streams, round 2) reaches on MI355X: fits 11.65 ms at
+    // N=20 x 512 x 16 periods, 3.05 ms at N=20 x 1024 x 1, 12.2 (measured 11.8) ms at N=24 x 256 x 1; DESIGN.md §4.
     const double cells = (double)p->L * (double)n_ch;
-    const double model_ms = cells * (double)periods * (double)is / 5.85e9 + cells * (double)dtype_size(p->dtype) / 5.2e9;
+    const double model_ms = cells * (double)periods * (double)is / 6.36e9 + cells * (double)dtype_size(p->dtype) / 5.05e9;
     PlacementStats st;
     rc = placement_search(ops, tries, model_ms, d_x, &st);
     (void)hipEventDestroy(ctx.ev[0]);
