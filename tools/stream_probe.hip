@@ -22,6 +22,38 @@ __global__ void __launch_bounds__(256) rd(const U4 *src, uint64_t n, uint32_t *s
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u && acc.x == 0x7F4A7C15u) *sink = acc.y;
 }
+// cache-policy bits by hand: POL 0 plain, 1 nt, 2 sc1, 3 sc1 nt, 4 sc0 sc1, 5 sc0 sc1 nt, 6 sc0, 7 sc0 nt
+template <int POL>
+__device__ __forceinline__ U4 ld_pol(const U4 *p)
+{
+    U4 v;
+    if constexpr (POL == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 6) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POL == 7) asm volatile("global_load_dwordx4 %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int POL>
+__global__ void __launch_bounds__(256) rd_pol(const U4 *src, uint64_t n, uint32_t *sink)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    U4 acc = (U4)0u;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+        U4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = ld_pol<POL>(src + i + k * stride);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc ^= t[k];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u && acc.x == 0x7F4A7C15u) *sink = acc.y;
+}
+
 template <int UNR, bool NT>
 __global__ void __launch_bounds__(256) cp(const U4 *src, U4 *dst, uint64_t n)
 {
@@ -85,6 +117,13 @@ int main(int argc, char **argv)
                2 * bytes / 1e6 / timeit([&] { cp<8, true><<<grid, 256>>>(a, b, n); }), 2 * bytes / 1e6 / timeit([&] { cp<4, false><<<grid, 256>>>(a, b, n); }),
                2 * bytes / 1e6 / timeit([&] { cp<4, true><<<grid, 256>>>(a, b, n); }), 2 * bytes / 1e6 / timeit([&] { cp<1, false><<<grid, 256>>>(a, b, n); }));
         printf("write %.0f  nt %.0f\n", bytes / 1e6 / timeit([&] { wr<false><<<grid, 256>>>(b, n); }), bytes / 1e6 / timeit([&] { wr<true><<<grid, 256>>>(b, n); }));
+    }
+    for (int grid : {2048, 16384}) {
+        printf("read by cache policy, grid %5d: plain %.0f  nt %.0f  sc1 %.0f  sc1 nt %.0f  sc0 sc1 %.0f  sc0 sc1 nt %.0f  sc0 %.0f  sc0 nt %.0f\n", grid,
+               bytes / 1e6 / timeit([&] { rd_pol<0><<<grid, 256>>>(a, n, (uint32_t *)b); }), bytes / 1e6 / timeit([&] { rd_pol<1><<<grid, 256>>>(a, n, (uint32_t *)b); }),
+               bytes / 1e6 / timeit([&] { rd_pol<2><<<grid, 256>>>(a, n, (uint32_t *)b); }), bytes / 1e6 / timeit([&] { rd_pol<3><<<grid, 256>>>(a, n, (uint32_t *)b); }),
+               bytes / 1e6 / timeit([&] { rd_pol<4><<<grid, 256>>>(a, n, (uint32_t *)b); }), bytes / 1e6 / timeit([&] { rd_pol<5><<<grid, 256>>>(a, n, (uint32_t *)b); }),
+               bytes / 1e6 / timeit([&] { rd_pol<6><<<grid, 256>>>(a, n, (uint32_t *)b); }), bytes / 1e6 / timeit([&] { rd_pol<7><<<grid, 256>>>(a, n, (uint32_t *)b); }));
     }
     for (int grid : {2048, 16384, 131072}) {
         const uint64_t per = n / grid;

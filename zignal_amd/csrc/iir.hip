@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int e = tid + i * 256, tt = e / CC, cc = e % CC;
-            r[i] = ((const double *)x)[(t0 + tt) * rs + (c0 + cc) * cs];
+            r[i] = __builtin_nontemporal_load((const double *)x + (t0 + tt) * rs + (c0 + cc) * cs);     // each sweep reads the signal once
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict
         for (int e = tid; e < TT * CC; e += 256) {
             const int tt = e / CC, cc = e % CC;
             const int64_t t = t0 + tt, ch = c0 + cc;
-            if (t < n_rows && ch < n_ch) y[t * ors + ch * ocs] = tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)];
+            if (t < n_rows && ch < n_ch) __builtin_nontemporal_store(tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)], y + t * ors + ch * ocs);
         }
     }
 }
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256, (S <= 5 ? 2 : 1)) iir_period_kernel(const
             }
             double *o = sum + (j0 + fr) * srs + c0 + cp;
 #pragma unroll
-            for (int i = 0; i < NV; ++i, o += 32 * srs) *(D2 *)o = acc2[i];
+            for (int i = 0; i < NV; ++i, o += 32 * srs) __builtin_nontemporal_store(acc2[i], (D2 *)o);
             return;
         }
     }

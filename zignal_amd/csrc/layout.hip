@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) sum_transpose_kernel(const TIN *__restric
             V o;
 #pragma unroll
             for (int e = 0; e < E; ++e) o[e] = tile[r][vv * E + e];
-            *(V *)(S + (j0 + r) * Cs + cb + vv * E) = o;
+            __builtin_nontemporal_store(o, (V *)(S + (j0 + r) * Cs + cb + vv * E));
         }
     }
 }
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict_
 #pragma unroll
     for (int r = r0; r < kTileRows; r += RPP) {
         V o = (V)(T)0;
-        if (j0 + r < L && cb + vv * E < Cs) o = *(const V *)(H + (j0 + r) * Cs + cb + vv * E);
+        if (j0 + r < L && cb + vv * E < Cs) o = __builtin_nontemporal_load((const V *)(H + (j0 + r) * Cs + cb + vv * E));
 #pragma unroll
         for (int e = 0; e < E; ++e) tile[r][vv * E + e] = o[e];
     }
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict_
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
         const int64_t ch = cb + wave * CPW + i;
-        if (j < L && ch < n_ch) out[ch * out_ch_stride + j] = tile[lane][wave * CPW + i];
+        if (j < L && ch < n_ch) __builtin_nontemporal_store(tile[lane][wave * CPW + i], out + ch * out_ch_stride + j);
     }
 }
 

@@ -49,12 +49,12 @@ __global__ void __launch_bounds__(256) period_sum_vec_kernel(const T *__restrict
         for (; p + PU <= periods; p += PU) {
             V t[PU];
 #pragma unroll
-            for (int i = 0; i < PU; ++i) t[i] = *(const V *)(src + (int64_t)(p + i) * pstep);
+            for (int i = 0; i < PU; ++i) t[i] = __builtin_nontemporal_load((const V *)(src + (int64_t)(p + i) * pstep));     // read once
 #pragma unroll
             for (int i = 0; i < PU; ++i) acc += t[i];       // period order, as numpy adds the rows
         }
-        for (; p < periods; ++p) acc += *(const V *)(src + (int64_t)p * pstep);
-        *(V *)(out + ((q * L + j) * vec_per_row + vv) * E) = acc;
+        for (; p < periods; ++p) acc += __builtin_nontemporal_load((const V *)(src + (int64_t)p * pstep));
+        __builtin_nontemporal_store(acc, (V *)(out + ((q * L + j) * vec_per_row + vv) * E));
     }
 }
 
