@@ -45,6 +45,7 @@ typedef enum {
 typedef enum { ZMLS_F64 = 0, ZMLS_F32 = 1, ZMLS_I16 = 2, ZMLS_I32 = 3 } zmls_dtype;
 
 typedef struct zmls_plan zmls_plan;
+typedef struct zmls_iir zmls_iir;     /* emphasis / de-emphasis filter, below */
 
 const char *zmls_last_error(void);
 int zmls_version(void);
@@ -138,6 +139,23 @@ int zmls_capture_alloc(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch,
 int zmls_capture_alloc_stats(zmls_plan *p, int in_dtype, int64_t n_rows, int64_t n_ch, int tries, void **d_x, float stats[8]);
 int zmls_capture_free(zmls_plan *p, void *d_x);
 
+/* ---- several sources at once: the multichannel measurement zignal's MLS class describes and leaves to the caller
+ * (mls.py:338-343: one MLS per output channel, different taps, played together; "keep track of which channel is paired
+ * with which MLS" when extracting). Replaces the loop of _MLS_base.get_impulse calls (mls.py:315-328), one per
+ * (recorded channel, source) pair, that a zignal user writes today. `plans`: one plan per source, same order, dtype and
+ * device, in the order the sources were appended. Response of source k, channel c, lag m:
+ *     d_h[k*source_stride + m*out_row_stride + c*out_ch_stride]   (elements of the plans' dtype).
+ * The periods are added up once for all sources when that moves fewer bytes than reading the capture once per source
+ * (the average does not depend on the taps); `f` non-null: the capture is de-emphasised first (MLS.apply_deemphasis,
+ * mls.py:401-407) through the single sweep of zmls_impulse_filtered_device, again once for all sources. The plans run
+ * one after the other and share plan 0's workspace and staging: zmls_sources_reserve(plans, n, f, n_rows, n_ch)
+ * allocates them (outside timed regions); the launch call never allocates or synchronises. */
+int zmls_sources_reserve(zmls_plan *const *plans, int n_plans, zmls_iir *f, int64_t n_rows, int64_t n_ch);
+int zmls_impulse_sources_device(zmls_plan *const *plans, int n_plans, zmls_iir *f, const void *d_x, int in_dtype,
+                                int64_t n_rows, int64_t n_ch, int64_t row_stride, int64_t ch_stride,
+                                void *d_h, int64_t source_stride, int64_t out_row_stride, int64_t out_ch_stride,
+                                void *hip_stream);
+
 /* ---- the averaging step alone: replaces trim_and_avgerage (mls.py:258-313) when it is called
  * on its own. out: (L, n_ch) C-contiguous HOST buffer, float32 when in_dtype is ZMLS_F32 (numpy
  * averages float32 in float32), float64 otherwise. */
@@ -199,7 +217,6 @@ int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d
  * whole stimulus / capture. Same transposed-direct-form-II arithmetic per sample, float64, zero initial state; the
  * recurrence is cut into blocks whose start states are put together with powers of the state matrix (iir.hip).
  * b, a: numerator / denominator as lfilter takes them (normalised by a[0] here); order max(nb, na)-1 <= 8. */
-typedef struct zmls_iir zmls_iir;
 int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, int na, int device);
 int zmls_iir_destroy(zmls_iir *f);
 /* scratch for signals of up to n_rows frames x n_ch channels (allocates; outside timed regions) */

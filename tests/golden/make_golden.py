@@ -318,13 +318,59 @@ def dump_fft():
     write_json("fft.json", {"cases": cases})
 
 
+def dump_multi_source():
+    """The multichannel recipe of the MLS docstring (mls.py:338-343) carried out with the reference: one MLS per output
+    channel (same order, different taps), their samples appended into one Audio, all sources played together into a
+    small mixing system (a short FIR + delay per (recorded channel, source) pair, plus noise), and get_impulse called
+    once per pair with the MLS it is paired with. Second half: the same with an emphasis filter on every source and
+    apply_deemphasis before get_impulse."""
+    from scipy.signal import lfilter
+    from zignal.filters.biquads import RBJ
+    arrays, cases = {}, []
+    for cid, (N, K, C, rep, seed, emphasis) in enumerate([(10, 3, 2, 4, 21, False), (11, 4, 3, 5, 22, False), (12, 2, 3, 2, 23, False),
+                                                           (10, 3, 2, 5, 24, True), (11, 2, 3, 3, 25, True)]):
+        fs = 48000
+        B, A = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=fs).get_coefficients() if emphasis else ((1, 0, 0), (1, 0, 0))
+        srcs = [MLS(N=N, taps=TAPS[N][k], fs=fs, repeats=rep, B=B, A=A) for k in range(K)]
+        if emphasis:
+            for m in srcs:
+                m.apply_emphasis()
+        stim = zignal.Audio(fs=fs, initialdata=srcs[0].samples)
+        stim.append(*[zignal.Audio(fs=fs, initialdata=m.samples) for m in srcs[1:]])
+        rng = np.random.default_rng(seed)
+        L = srcs[0].L
+        x = 0.01 * rng.standard_normal((rep * L, C))
+        for c in range(C):
+            for k in range(K):
+                fir = rng.standard_normal(12) * np.exp(-np.arange(12) / 3.0)
+                delay = int(rng.integers(0, L // 2))
+                # the sources repeat, so a circular shift of the steady state is what a delay does to all periods but the first
+                x[:, c] += np.roll(lfilter(fir, [1.0], stim.samples[:, k]), delay)
+        key = "m%d" % cid
+        h = np.empty((K, L, C))
+        for k in range(K):
+            for c in range(C):
+                col = x[:, c:c + 1]
+                if emphasis:
+                    col = srcs[k].apply_deemphasis(col)
+                h[k, :, c] = srcs[k].get_impulse(col).samples[:, 0]
+        arrays[key + "_x"], arrays[key + "_h"] = x, h
+        if N == 10:
+            arrays[key + "_stim"] = stim.samples.copy()
+        cases.append({"id": key, "N": N, "taps": [list(TAPS[N][k]) for k in range(K)], "channels": C, "repeats": rep, "fs": fs,
+                      "seed": seed, "emphasis": emphasis, "B": [float(v) for v in B], "A": [float(v) for v in A],
+                      "x_sha256": inputs.digest(x)})
+    np.savez_compressed(os.path.join(HERE, "multi_source.npz"), **arrays)
+    write_json("multi_source.json", {"cases": cases})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     steps = {"taps": dump_taps, "errors": dump_errors, "api": dump_api, "fft": dump_fft,
-             "seq": lambda: dump_seq_kats(a.quick), "prefix": dump_seq_prefix, "simple_short": dump_simple_short, "ir": lambda: dump_ir(a.quick)}
+             "seq": lambda: dump_seq_kats(a.quick), "prefix": dump_seq_prefix, "simple_short": dump_simple_short, "multi": dump_multi_source, "ir": lambda: dump_ir(a.quick)}
     for name, fn in steps.items():
         if a.only and name not in a.only.split(","):
             continue

@@ -230,3 +230,24 @@ def test_argument_errors_need_no_device(lib):
     assert lib.zmls_plan_info(None, None) == _lib.E_ARG
     assert lib.zmls_plan_force_tile(None, 0) == _lib.E_ARG
     assert b"" != _lib.last_error().encode()
+    assert lib.zmls_impulse_sources_device(None, 2, None, None, 0, 8, 1, 1, 1, None, 1, 1, 1, None) == _lib.E_ARG
+    assert lib.zmls_sources_reserve((ctypes.c_void_p * 2)(None, None), 2, None, 8, 1) == _lib.E_ARG and "null" in _lib.last_error()
+    assert lib.zmls_sources_reserve((ctypes.c_void_p * 1)(None), 65, None, 8, 1) == _lib.E_ARG
+
+
+def test_audio_append_builds_the_multichannel_stimulus():
+    """Audio.append as the reference's multichannel recipe uses it (audio.py:376-421, mls.py:338-343): channels to the
+    right, the shorter side padded with zeros, mismatching rates and types refused."""
+    from zignal_amd.audio import Audio
+    a = Audio(fs=48000, initialdata=np.arange(6.0).reshape(6, 1))
+    b = Audio(fs=48000, initialdata=np.ones((4, 2)))
+    a.append(b, Audio(fs=48000, initialdata=np.full((8, 1), 7.0)))
+    assert a.samples.shape == (8, 4) and a.ch == 4 and a.nofsamples == 8 and a.duration == 8 / 48000
+    assert a.samples[:, 0].tolist() == [0, 1, 2, 3, 4, 5, 0, 0]
+    assert a.samples[:, 1].tolist() == [1, 1, 1, 1, 0, 0, 0, 0] and a.samples[:, 3].tolist() == [7] * 8
+    with pytest.raises(AssertionError):
+        a.append(Audio(fs=44100, initialdata=np.zeros((8, 1))))
+    with pytest.raises(AssertionError):
+        a.append(Audio(fs=48000, initialdata=np.zeros((8, 1), dtype=np.float32)))
+    with pytest.raises(AssertionError):
+        a.append(np.zeros((8, 1)))

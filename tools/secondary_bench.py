@@ -72,3 +72,22 @@ two = timed(lambda: (f.filter_device(x1.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, y1.p
                      p.impulse_device(y1.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, h1.ptr, 1, 1)), 5)
 one = timed(lambda: p.impulse_filtered_device(f, x1.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, h1.ptr, 1, 1), 5)
 print("de-emphasis + impulse, N=%d, one channel x %d periods (the reference's shape): filter then transform %8.3f ms, fused %8.3f ms" % (N, R, two, one), flush=True)
+
+# several sources at once (mls.py:338-343): K plans over one capture, one call per source against zmls_impulse_sources_device
+from zignal_amd.device import Sources
+for K, Rk in ((4, 17), (4, 5), (2, 17), (4, 2)):
+    plans = [p] + [Plan(N, TAPS[N][k], device=0) for k in range(1, K)]
+    for q in plans[1:]:
+        q.reserve(C)
+    hk = DeviceBuffer(K * L * C * 8)
+    each = timed(lambda: [q.impulse_device(x.ptr, _lib.ZMLS_F64, Rk * L, C, C, 1, hk.ptr + k * L * C * 8, C, 1) for k, q in enumerate(plans)], 3)
+    grp = Sources(plans)
+    grp.reserve(Rk * L, C)
+    once = timed(lambda: grp.impulse_device(x.ptr, _lib.ZMLS_F64, Rk * L, C, C, 1, hk.ptr, L * C, C, 1), 3)
+    grp.reserve(Rk * L, C, iir=f)
+    once_f = timed(lambda: grp.impulse_device(x.ptr, _lib.ZMLS_F64, Rk * L, C, C, 1, hk.ptr, L * C, C, 1, iir=f), 3)
+    print("sources  N=%d x %d channels x %d periods, %d sources: one call per source %8.3f ms, one call %8.3f ms (%.0f GB/s of capture read + responses written); "
+          "with de-emphasis %8.3f ms" % (N, C, Rk, K, each, once, ((Rk - 1) + K) * L * C * 8 / once / 1e6, once_f), flush=True)
+    hk.free()
+    for q in plans[1:]:
+        q.close()

@@ -68,6 +68,8 @@ SIGNATURES = {
     "zmls_iir_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],
     "zmls_iir_reserve_fused": [c_vp, c_vp, c_i64, c_i64],
     "zmls_impulse_filtered_device": [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],
+    "zmls_sources_reserve": [_vpp, c_int, c_vp, c_i64, c_i64],
+    "zmls_impulse_sources_device": [_vpp, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
     "zmls_iir_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp],
     "zmls_spectrum_create": [_vpp, c_i64, c_i64, c_int],
     "zmls_spectrum_destroy": [c_vp],

@@ -47,6 +47,23 @@ class Audio(object):
     def copy(self):
         return Audio(fs=self.fs, initialdata=self.samples)
 
+    def append(self, *args):
+        """Add the channels of other Audio instances to the right of the current ones; the shorter side is padded with
+        zeros (audio.py:376-421). This is how the reference builds a multichannel stimulus out of several MLS
+        (mls.py:338-343)."""
+        for other in args:
+            assert isinstance(other, Audio), "only Audio() instances can be used"
+            assert self.fs == other.fs, "Sample rates must match (%s != %s)" % (self.fs, other.fs)
+            assert self.samples.dtype == other.samples.dtype, \
+                "Data types must match (%s != %s)" % (self.samples.dtype, other.samples.dtype)
+            rows = max(self.nofsamples, other.nofsamples)
+            both = np.zeros((rows, self.ch + other.ch), dtype=self.samples.dtype)
+            both[:self.nofsamples, :self.ch] = self.samples
+            both[:other.nofsamples, self.ch:] = other.samples
+            self.samples = both
+            self.nofsamples, self.ch = both.shape
+            self.duration = self.nofsamples / self.fs
+
     # -- sample formats (host side; the MLS path can take the integers directly: get_impulse_pcm) ----------
     def convert_to_float(self, targetbits=64):
         """Integers -> floats in [-1, 1): samples / 2^(sourcebits-1), in place (audio.py:565-589)."""

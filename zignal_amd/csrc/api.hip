@@ -514,6 +514,23 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
     return ZMLS_OK;
 }
 
+// the passes on one channel chunk, and the way out: straight into the caller's responses, or - responses contiguous in
+// time - into the second staging array and transposed from there. Pad columns ride along when both sides are staged.
+static int passes_and_layout_out(zmls_plan *p, const Scratch &sc, const void *src, int src_dtype, int64_t src_periods, int src_skip,
+                                 int64_t divisor, int64_t n, int64_t Cs, bool staged_in, int64_t src_rs, int64_t src_cs, void *d_h,
+                                 int64_t out_row_stride, int64_t out_ch_stride, bool out_cm, hipStream_t st, hipEvent_t *ev, float *pass_ms)
+{
+    const int64_t n_pass = (staged_in && out_cm) ? Cs : n;
+    void *dst = d_h;
+    int64_t dst_rs = out_row_stride, dst_cs = out_ch_stride;
+    if (out_cm) { dst = sc.stage[1]; dst_rs = Cs; dst_cs = 1; }
+    int rc = run_passes(p, src, src_dtype, src_periods, src_skip, divisor, n_pass, src_rs, src_cs, dst, dst_rs, dst_cs, st, ev, pass_ms, 0,
+                        sc.work, sc.work_bytes);
+    if (rc) return rc;
+    if (out_cm) rc = launch_transpose_out(sc.stage[1], p->dtype, p->L, Cs, n, d_h, out_ch_stride, st);
+    return rc;
+}
+
 // Layout adapters (layout.hip, period_sum.hip) around run_passes for multi-pass plans:
 //   time-contiguous captures (a stack of single-channel arrays; also the reference's own (n,) and (n,1) inputs)
 //       -> periods summed and transposed into a frame-major staging array of sums, passes on that
@@ -523,10 +540,15 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
 // Without staging (zmls_plan_reserve_staging) everything still works through the element path, slowly.
 int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
                         int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
-                        int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms, int gather_pass_only)
+                        int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms, int gather_pass_only,
+                        const Scratch *shared)
 {
     if (!p || !d_x || (!d_h && !gather_pass_only)) { set_error("null argument"); return ZMLS_E_ARG; }
     if (int rc = sequence_only(p)) return rc;
+    void *const work = shared ? shared->work : nullptr;
+    const size_t work_bytes = shared ? shared->work_bytes : 0;
+    void *const *stage = shared ? shared->stage : p->d_stage;
+    const size_t stage_bytes = shared ? shared->stage_bytes : p->stage_bytes;
     const size_t is = dtype_size(in_dtype), ts = dtype_size(p->dtype);
     if (!is) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
     if (n_ch < 1) { set_error("need at least one channel"); return ZMLS_E_ARG; }
@@ -537,40 +559,47 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
                         ((uintptr_t)d_x % kVecBytes) == 0 && n_ch % E == 0;
     const bool vec_out = out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 && ((uintptr_t)d_h % kVecBytes) == 0 && n_ch % E == 0;
     const int64_t per_ch = p->L * (int64_t)ts;                                    // staging bytes per channel
-    int64_t cc = (int64_t)(p->stage_bytes / (size_t)per_ch) / E * E;              // channels a staging array holds
+    int64_t cc = (int64_t)(stage_bytes / (size_t)per_ch) / E * E;                 // channels a staging array holds
     const bool in_cm = multi && !vec_in && row_stride == 1 && cc >= E;
     const bool in_fm = multi && !vec_in && !in_cm && ch_stride == 1 && cc >= E;
     const bool out_cm = multi && !vec_out && out_row_stride == 1 && cc >= E;
     if (!in_cm && !in_fm && !out_cm)
         return run_passes(p, d_x, in_dtype, periods, skip_periods, divisor, n_ch, row_stride, ch_stride, d_h, out_row_stride, out_ch_stride,
-                          st, ev, pass_ms, gather_pass_only, nullptr, 0);
+                          st, ev, pass_ms, gather_pass_only, work, work_bytes);
     ZDEVICE(p->device);
+    const Scratch own = {work, work_bytes, {stage[0], stage[1]}, stage_bytes};
     int rc = ZMLS_OK;
     for (int64_t c0 = 0; c0 < n_ch; c0 += cc) {
         const int64_t n = (n_ch - c0 < cc) ? n_ch - c0 : cc;
         const int64_t Cs = (n + E - 1) / E * E;
-        const bool both = (in_cm || in_fm) && out_cm;
-        const int64_t n_pass = both ? Cs : n;                                     // pad columns ride along when both sides are staged
         const void *src = (const char *)d_x + (size_t)(c0 * ch_stride) * is;
         int src_dtype = in_dtype, src_skip = skip_periods;
         int64_t src_periods = periods, src_rs = row_stride, src_cs = ch_stride;
         if (in_cm || in_fm) {
-            if (in_cm) rc = launch_sum_transpose(d_x, in_dtype, p->dtype, p->L, periods, skip_periods, ch_stride, c0, n_ch, p->d_stage[0], Cs, st);
-            else rc = launch_period_sum(d_x, in_dtype, p->dtype, p->L, periods, skip_periods, row_stride, 1, 1, 0, c0, Cs, n_ch, p->d_stage[0], st);
+            if (in_cm) rc = launch_sum_transpose(d_x, in_dtype, p->dtype, p->L, periods, skip_periods, ch_stride, c0, n_ch, stage[0], Cs, st);
+            else rc = launch_period_sum(d_x, in_dtype, p->dtype, p->L, periods, skip_periods, row_stride, 1, 1, 0, c0, Cs, n_ch, stage[0], st);
             if (rc) return rc;
-            src = p->d_stage[0]; src_dtype = p->dtype; src_skip = 0; src_periods = 1; src_rs = Cs; src_cs = 1;
+            src = stage[0]; src_dtype = p->dtype; src_skip = 0; src_periods = 1; src_rs = Cs; src_cs = 1;
         }
-        void *dst = (char *)d_h + (size_t)(c0 * out_ch_stride) * ts;
-        int64_t dst_rs = out_row_stride, dst_cs = out_ch_stride;
-        if (out_cm) { dst = p->d_stage[1]; dst_rs = Cs; dst_cs = 1; }
-        rc = run_passes(p, src, src_dtype, src_periods, src_skip, divisor, n_pass, src_rs, src_cs, dst, dst_rs, dst_cs, st, ev, pass_ms, 0, nullptr, 0);
+        rc = passes_and_layout_out(p, own, src, src_dtype, src_periods, src_skip, divisor, n, Cs, in_cm || in_fm, src_rs, src_cs,
+                                   (char *)d_h + (size_t)(c0 * out_ch_stride) * ts, out_row_stride, out_ch_stride, out_cm, st, ev, pass_ms);
         if (rc) return rc;
-        if (out_cm) {
-            rc = launch_transpose_out(p->d_stage[1], p->dtype, p->L, Cs, n, (char *)d_h + (size_t)(c0 * out_ch_stride) * ts, out_ch_stride, st);
-            if (rc) return rc;
-        }
     }
     return ZMLS_OK;
+}
+
+// One period of sums already in a staging-shaped array (L frames x Cs channels of the plan's dtype, Cs a whole number of
+// vectors, columns n..Cs-1 zero): what impulse_device_core does after its own staging step. For callers that made the
+// sums themselves (sources.hip: one set of sums, several plans).
+int staged_sums_to_responses(zmls_plan *p, const Scratch &sc, const void *d_sums, int64_t Cs, int64_t divisor, int64_t n, void *d_h,
+                             int64_t out_row_stride, int64_t out_ch_stride, hipStream_t st)
+{
+    const size_t ts = dtype_size(p->dtype);
+    const int E = (int)(kVecBytes / ts);
+    const bool vec_out = out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 && ((uintptr_t)d_h % kVecBytes) == 0 && n % E == 0;
+    const bool out_cm = p->npass > 1 && !vec_out && out_row_stride == 1 && sc.stage[1] && sc.stage_bytes >= (size_t)p->L * (size_t)Cs * ts;
+    return passes_and_layout_out(p, sc, d_sums, p->dtype, 1, 0, divisor, n, Cs, true, Cs, 1, d_h, out_row_stride, out_ch_stride, out_cm, st,
+                                 nullptr, nullptr);
 }
 } // namespace zmls
 

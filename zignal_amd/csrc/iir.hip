@@ -577,6 +577,52 @@ struct zmls_iir {
 
 using namespace zmls;
 
+// The capture swept once: periods 1..R-1 added up, the filter's state at every period boundary beside it; then the
+// filter over the one period of sums from the summed states. Leaves the filtered sums in the filter's own array.
+int zmls::filtered_period_sums(zmls_plan *p, zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
+                               int64_t ch_stride, const double **sums, int64_t *out_srs, int64_t *out_scs, hipStream_t st)
+{
+    if (!p || !f || !d_x) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (p->device != f->device) { set_error("plan is on device %d, filter on device %d", p->device, f->device); return ZMLS_E_ARG; }
+    if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
+    if (n_ch < 1 || row_stride < 1 || ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
+    int64_t periods = 0;
+    int rc = capture_periods(p, n_rows, &periods);
+    if (rc) return rc;
+    if (int rc0 = sequence_only(p)) return rc0;
+    ZDEVICE(f->device);
+    const int64_t L = p->L, R = periods + 1;
+    const bool tc = row_stride == 1 && (n_ch == 1 || ch_stride != 1);
+    const int64_t tt = (256 / (tc ? 1 : 16)) * kIirSub;
+    const size_t n_chunks = (size_t)((L + tt - 1) / tt);
+    if ((size_t)(R - 1) * n_chunks * (size_t)n_ch * (size_t)f->S > f->e_elems || (size_t)L * (size_t)n_ch > f->sum_elems ||
+        (size_t)n_ch * (size_t)f->S > f->zi_elems || f->phi_L != L) {
+        set_error("call zmls_iir_reserve_fused(filter, plan, n_rows, n_ch) first");
+        return ZMLS_E_WORKSPACE;
+    }
+    // the sums keep the layout class of the capture: (L, n_ch) frames x channels, or n_ch runs of L frames
+    const int64_t srs = tc ? 1 : n_ch, scs = tc ? L : 1;
+#define ZPER(SS) case SS: rc = tc ? launch_period_s<SS, 1>(f->d_f, d_x, in_dtype, L, R, n_ch, row_stride, ch_stride, f->d_e, f->d_E, f->d_phi, f->d_zi, f->d_sum, srs, scs, st) \
+                                  : launch_period_s<SS, 16>(f->d_f, d_x, in_dtype, L, R, n_ch, row_stride, ch_stride, f->d_e, f->d_E, f->d_phi, f->d_zi, f->d_sum, srs, scs, st); break;
+#define ZFIL(SS) case SS: rc = launch_iir_cc<SS>(tc, f->d_f, f->d_sum, ZMLS_F64, L, n_ch, srs, scs, f->d_zc, f->d_sin, f->d_zg, f->d_sg, f->d_sum, srs, scs, f->d_zi, st); break;
+    switch (f->S) {
+        ZPER(1) ZPER(2) ZPER(3) ZPER(4) ZPER(5) ZPER(6) ZPER(7) ZPER(8)
+    default: set_error("no filter kernel for order %d", f->S); return ZMLS_E_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    switch (f->S) {
+        ZFIL(1) ZFIL(2) ZFIL(3) ZFIL(4) ZFIL(5) ZFIL(6) ZFIL(7) ZFIL(8)
+    default: break;
+    }
+#undef ZPER
+#undef ZFIL
+    if (rc) return rc;
+    *sums = f->d_sum;
+    *out_srs = srs;
+    *out_scs = scs;
+    return ZMLS_OK;
+}
+
 extern "C" {
 
 int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, int na, int device)
@@ -741,44 +787,15 @@ int zmls_iir_reserve_fused(zmls_iir *f, zmls_plan *p, int64_t n_rows, int64_t n_
 int zmls_impulse_filtered_device(zmls_plan *p, zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
                                  int64_t ch_stride, void *d_h, int64_t out_row_stride, int64_t out_ch_stride, void *stream)
 {
-    if (!p || !f || !d_x || !d_h) { set_error("null argument"); return ZMLS_E_ARG; }
-    if (p->device != f->device) { set_error("plan is on device %d, filter on device %d", p->device, f->device); return ZMLS_E_ARG; }
-    if (!dtype_size(in_dtype)) { set_error("unknown input dtype %d", in_dtype); return ZMLS_E_ARG; }
-    if (n_ch < 1 || row_stride < 1 || ch_stride < 1 || out_row_stride < 1 || out_ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
-    int64_t periods = 0;
-    int rc = capture_periods(p, n_rows, &periods);
-    if (rc) return rc;
-    if (int rc0 = sequence_only(p)) return rc0;
-    ZDEVICE(f->device);
-    const int64_t L = p->L, R = periods + 1;
-    const bool tc = row_stride == 1 && (n_ch == 1 || ch_stride != 1);
-    const int64_t tt = (256 / (tc ? 1 : 16)) * kIirSub;
-    const size_t n_chunks = (size_t)((L + tt - 1) / tt);
-    if ((size_t)(R - 1) * n_chunks * (size_t)n_ch * (size_t)f->S > f->e_elems || (size_t)L * (size_t)n_ch > f->sum_elems ||
-        (size_t)n_ch * (size_t)f->S > f->zi_elems || f->phi_L != L) {
-        set_error("call zmls_iir_reserve_fused(filter, plan, n_rows, n_ch) first");
-        return ZMLS_E_WORKSPACE;
-    }
+    if (!d_h) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (out_row_stride < 1 || out_ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
+    const double *sums = nullptr;
+    int64_t srs = 0, scs = 0;
     hipStream_t st = (hipStream_t)stream;
-    // the sums keep the layout class of the capture: (L, n_ch) frames x channels, or n_ch runs of L frames
-    const int64_t srs = tc ? 1 : n_ch, scs = tc ? L : 1;
-#define ZPER(SS) case SS: rc = tc ? launch_period_s<SS, 1>(f->d_f, d_x, in_dtype, L, R, n_ch, row_stride, ch_stride, f->d_e, f->d_E, f->d_phi, f->d_zi, f->d_sum, srs, scs, st) \
-                                  : launch_period_s<SS, 16>(f->d_f, d_x, in_dtype, L, R, n_ch, row_stride, ch_stride, f->d_e, f->d_E, f->d_phi, f->d_zi, f->d_sum, srs, scs, st); break;
-#define ZFIL(SS) case SS: rc = launch_iir_cc<SS>(tc, f->d_f, f->d_sum, ZMLS_F64, L, n_ch, srs, scs, f->d_zc, f->d_sin, f->d_zg, f->d_sg, f->d_sum, srs, scs, f->d_zi, st); break;
-    switch (f->S) {
-        ZPER(1) ZPER(2) ZPER(3) ZPER(4) ZPER(5) ZPER(6) ZPER(7) ZPER(8)
-    default: set_error("no filter kernel for order %d", f->S); return ZMLS_E_UNSUPPORTED;
-    }
-    if (rc) return rc;
-    switch (f->S) {
-        ZFIL(1) ZFIL(2) ZFIL(3) ZFIL(4) ZFIL(5) ZFIL(6) ZFIL(7) ZFIL(8)
-    default: break;
-    }
-#undef ZPER
-#undef ZFIL
+    int rc = filtered_period_sums(p, f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, &sums, &srs, &scs, st);
     if (rc) return rc;
     // one period of filtered sums -> divided by the period count in the gather, transformed, scattered
-    return impulse_device_core(p, f->d_sum, ZMLS_F64, 1, 0, periods, n_ch, srs, scs, d_h, out_row_stride, out_ch_stride, st, nullptr, nullptr, 0);
+    return impulse_device_core(p, sums, ZMLS_F64, 1, 0, n_rows / p->L - 1, n_ch, srs, scs, d_h, out_row_stride, out_ch_stride, st, nullptr, nullptr, 0);
 }
 
 int zmls_iir_host(zmls_iir *f, const void *x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride, int64_t ch_stride, double *y)

@@ -93,10 +93,20 @@ struct PassArgs {
     double out_scale;         // 1/L, times 2^-k for raw PCM captures (zmls_plan_set_input_scale_log2)
 };
 
-// the launch sequence of one impulse-response batch (api.hip); ev/pass_ms null unless timed
+// Device scratch of a launch sequence: the intermediate between the passes and the two layout staging arrays. A plan
+// brings its own; plans that run one after the other on one capture (several sources, sources.hip) share one set.
+struct Scratch { void *work; size_t work_bytes; void *stage[2]; size_t stage_bytes; };
+// the launch sequence of one impulse-response batch (api.hip); ev/pass_ms null unless timed; shared null: the plan's own scratch
 int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
                         int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,
-                        int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms, int gather_pass_only);
+                        int64_t out_ch_stride, hipStream_t st, hipEvent_t *ev, float *pass_ms, int gather_pass_only,
+                        const Scratch *shared = nullptr);
+// the same from one period of sums the caller has staged (L x Cs frames x channels of the plan's dtype, n of them valid)
+int staged_sums_to_responses(zmls_plan *p, const Scratch &sc, const void *d_sums, int64_t Cs, int64_t divisor, int64_t n, void *d_h,
+                             int64_t out_row_stride, int64_t out_ch_stride, hipStream_t st);
+// one period of de-emphasised period sums of a capture (iir.hip): *sums is float64, element (j, c) at j*srs + c*scs
+int filtered_period_sums(zmls_plan *p, zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
+                         int64_t ch_stride, const double **sums, int64_t *srs, int64_t *scs, hipStream_t st);
 // the passes on buffers as they are (no layout adapters); work = null: the plan's own workspace
 int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int skip_periods, int64_t divisor,
                int64_t n_ch, int64_t row_stride, int64_t ch_stride, void *d_h, int64_t out_row_stride,

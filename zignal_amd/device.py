@@ -211,6 +211,50 @@ class Plan:
         return np.array(list(taps)), d.value
 
 
+class Sources:
+    """Several MLS sources of one order played at once and recorded together: the multichannel measurement the reference
+    describes and leaves to the caller (mls.py:338-343). `plans`: one Plan per source (same N, dtype, device), in source
+    order. One call extracts the responses of every (source, recorded channel) pair; the periods are added up once for all
+    sources when that moves fewer bytes, and the plans share the first plan's workspace (zmls_impulse_sources_device)."""
+
+    def __init__(self, plans):
+        self.plans = list(plans)
+        if not self.plans:
+            raise ValueError("at least one source plan")
+        p0 = self.plans[0]
+        self.device, self.np_dtype, self.L = p0.device, p0.np_dtype, p0.L
+        self._arr = (ctypes.c_void_p * len(self.plans))(*[p._h for p in self.plans])
+
+    def __len__(self):
+        return len(self.plans)
+
+    def reserve(self, n_rows, n_ch, iir=None):
+        L.check(L.lib().zmls_sources_reserve(self._arr, len(self.plans), None if iir is None else iir._h, int(n_rows), int(n_ch)))
+
+    def impulse_device(self, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_h, source_stride, out_row_stride, out_ch_stride,
+                       iir=None, stream=None):
+        L.check(L.lib().zmls_impulse_sources_device(self._arr, len(self.plans), None if iir is None else iir._h, d_x, in_dtype,
+                                                    int(n_rows), int(n_ch), int(row_stride), int(ch_stride), d_h, int(source_stride),
+                                                    int(out_row_stride), int(out_ch_stride), stream))
+
+    def impulse_host(self, x, iir=None):
+        """x: (R*L,) or (R*L, C) capture -> (K, L, C) of the plans' dtype: [k, :, c] is what plan k's get_impulse returns
+        for column c (after de-emphasis with `iir`, when given)."""
+        x2, code, n_rows, n_ch, rs, cs = Plan._as_capture(np.asarray(x))
+        K, es = len(self.plans), np.dtype(self.np_dtype).itemsize
+        self.reserve(n_rows, n_ch, iir)
+        d_x = DeviceBuffer(((n_rows - 1) * rs + (n_ch - 1) * cs + 1) * x2.itemsize, self.device)
+        d_h = DeviceBuffer(K * self.L * n_ch * es, self.device)
+        try:
+            L.check(L.lib().zmls_dev_upload(self.device, d_x.ptr, x2.ctypes.data, d_x.nbytes))
+            self.impulse_device(d_x.ptr, code, n_rows, n_ch, rs, cs, d_h.ptr, self.L * n_ch, n_ch, 1, iir=iir)
+            sync(self.device)
+            return d_h.download((K, self.L, n_ch), self.np_dtype)
+        finally:
+            d_x.free()
+            d_h.free()
+
+
 class IirFilter:
     """lfilter(B, A, x, axis=0) on the GPU (zmls_iir_*): what MLS.apply_emphasis / apply_deemphasis run
     (zignal/measure/mls.py:393-407, zignal/filters/linearfilter.py:62-63). Orders up to 8."""
