@@ -2,5 +2,5 @@
 # kernel trace of the kernels either side of the headline path (tools/secondary_bench.py), round 2
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r02_secondary -- python3 $R/tools/secondary_bench.py > $R/gpurun_out/secondary_r02.txt || exit 1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r02_secondary -- python3 $R/tools/secondary_bench.py > $R/gpurun_out/secondary_r02.txt 2> $R/gpurun_out/secondary_r02.err || exit 1
 echo done
