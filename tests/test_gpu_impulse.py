@@ -473,3 +473,41 @@ def test_capture_alloc_stats_and_free_through_the_c_abi():
     assert lib.zmls_capture_free(p._h, ptr) == 0
     assert lib.zmls_capture_free(p._h, None) == 0 and lib.zmls_capture_free(None, None) == _lib.E_ARG
     assert lib.zmls_capture_alloc_stats(p._h, _lib.ZMLS_F64, p.L, 8, 0, ctypes.byref(ptr), stats) == _lib.E_ARG      # one period: nothing to average
+
+
+@pytest.mark.parametrize("np_in,plan_dtype", [(np.int16, "f64"), (np.int32, "f64"), (np.float32, "f64"), (np.int16, "f32"), (np.int32, "f32"),
+                                              (np.float64, "f32")])
+@pytest.mark.parametrize("N,C,R", [(12, 24, 6), (13, 64, 3), (12, 8, 11)])
+def test_frame_major_captures_of_other_sample_types_take_the_vector_adapter(np_in, plan_dtype, N, C, R):
+    """(frames, channels) captures whose sample type is not the plan's - raw PCM, float32 into a float64 plan, float64 into a
+    float32 plan - are added up by period_sum_cvt_kernel (16-byte loads, converted in registers). Same additions in the same order
+    as the element adapter, which the same capture takes as soon as its rows are padded by one sample: bit-identical; and the
+    oracle on the converted capture."""
+    taps = TAPS[N][0]
+    p = plan(N, taps, plan_dtype)
+    L = p.L
+    rng = np.random.default_rng(N * 1000 + C + R)
+    seq = c_oracle.sequence(N, taps)[:, 0]
+    x = np.stack([np.tile(np.roll(seq, 37 * c + 1), R) * (0.2 + 0.01 * c) for c in range(C)], axis=1) + 0.05 * rng.standard_normal((R * L, C))
+    if np.issubdtype(np_in, np.integer):
+        x = np.round(x * (np.iinfo(np_in).max / 4.0)).astype(np_in)
+    else:
+        x = x.astype(np_in)
+    code = _lib.dtype_code(np_in)
+    p.reserve(C, staging=True)
+    es_out = np.dtype(p.np_dtype).itemsize
+    d_h = DeviceBuffer(L * C * es_out, 0)
+    got = []
+    for pad in (0, 1):                                   # pad 1: rows of C+1 samples, not a whole number of vectors -> element adapter
+        xd = np.zeros((R * L, C + pad), dtype=np_in)
+        xd[:, :C] = x
+        d_x = DeviceBuffer(xd.nbytes, 0).upload(xd)
+        p.impulse_device(d_x.ptr, code, R * L, C, C + pad, 1, d_h.ptr, C, 1)
+        _lib.check(_lib.lib().zmls_dev_sync(0))
+        got.append(d_h.download((L, C), p.np_dtype))
+        d_x.free()
+    d_h.free()
+    assert np.array_equal(got[0], got[1])
+    tol = TOL32 if (plan_dtype == "f32" or np_in == np.float32) else TOL64
+    for c in (0, C // 2, C - 1):
+        assert rel_err(got[0][:, c], oracle_ir(N, taps, x[:, c:c + 1].astype(np.float64))) <= tol

@@ -92,6 +92,35 @@ def test_period_sums_in_the_exchange_layout_chunk_by_chunk(P, chunk):
     d_x.free()
 
 
+@pytest.mark.parametrize("np_in,plan_dtype", [(np.int16, "f64"), (np.int32, "f64"), (np.float32, "f64"), (np.int16, "f32"), (np.float64, "f32")])
+@pytest.mark.parametrize("P,share,chunk", [(1, 16, 16), (2, 64, 32), (4, 1024, 512), (4, 24, 8), (2, 512, 512)])
+def test_period_sums_of_other_sample_types_in_the_exchange_layout(np_in, plan_dtype, P, share, chunk):
+    """the converting vector kernel (period_sum_cvt_kernel) in the layouts the exchange asks for: one block, blocks whose rows are
+    whole waves of lanes (stores transposed through LDS) and blocks whose rows are not (strided stores); exact integer sums for
+    PCM, sums in the plan's precision otherwise"""
+    N, R = 7, 4
+    p = plan(N, TAPS[N][0], plan_dtype)
+    L, C = p.L, P * share
+    rng = np.random.default_rng(P * share + chunk)
+    if np.issubdtype(np_in, np.integer):
+        x = rng.integers(-3000, 3000, size=(R * L, C)).astype(np_in)
+    else:
+        x = rng.standard_normal((R * L, C)).astype(np_in)
+    d_x = DeviceBuffer(x.nbytes).upload(x)
+    acc = np.zeros((L, C), dtype=p.np_dtype)
+    for r in range(1, R):
+        acc += x[r * L:(r + 1) * L].astype(p.np_dtype)              # period order, in the plan's precision
+    for k in range(share // chunk):
+        d_s = DeviceBuffer(P * L * chunk * acc.itemsize)
+        d_s.fill(0xFF)
+        multi.period_sum_device(p, d_x.ptr, _lib.dtype_code(np_in), R * L, 1, C, 1, P, share, k * chunk, chunk, d_s.ptr)
+        got = d_s.download((P, L, chunk), p.np_dtype)
+        for q in range(P):
+            assert np.array_equal(got[q], acc[:, q * share + k * chunk:q * share + (k + 1) * chunk]), (k, q)
+        d_s.free()
+    d_x.free()
+
+
 @pytest.mark.parametrize("P,N,C,R,chunk,dtype", [(2, 12, 48, 5, 8, "f64"), (4, 14, 64, 9, 16, "f64"), (8, 10, 64, 3, 3, "f64"), (3, 13, 48, 7, 16, "f32"),
                                                   (4, 16, 128, 4, 8, "f64")])
 def test_fused_entry_point_on_several_ranks_through_the_loopback_transport(P, N, C, R, chunk, dtype):
