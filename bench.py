@@ -648,6 +648,14 @@ def main():
         roof["stream_calibration"] = ("hand-written 16 B/lane kernels over %.1f GB of the capture buffer in this run: read-only sweep, "
                                       "and copy of one half onto the other (bytes read + written)" % (cal[2] / 1e9))
         roof["frac_of_same_run_read_rate"] = achieved / cal[0]
+        # what the step would take if every stream ran at the rate of the calibration kernel of its kind: the capture read at the
+        # read-only rate; the intermediate (written, read back) and the responses (written) at the copy rate, which counts bytes
+        # read + written. Two passes only (N <= 20): the intermediate makes one round trip.
+        if len(pass_ms) == 2 and args.mode == "channel":
+            cells = L * C * es
+            bound_ms = (Ravg * cells / cal[0] + 3 * cells / cal[1]) / 1e6
+            roof["same_run_streaming_bound_ms"] = bound_ms
+            roof["frac_of_same_run_streaming_bound"] = bound_ms / pipeline_ms
     prof = profiled_traffic(dict(out["config"], dtype=args.dtype))
     if prof:
         out["roofline"]["traffic"] = prof[0]
