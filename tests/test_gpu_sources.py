@@ -288,3 +288,62 @@ def test_full_size_sources():
         assert np.max(np.abs(rest + 1.0 / L)) <= 1e-12
     for q in (d_x, d_h, d_ref):
         q.free()
+
+
+def _random_source_cases():
+    rng = np.random.default_rng(20261111)
+    out = []
+    for i in range(36):
+        N = int(rng.choice([7, 9, 10, 11, 12, 13, 14, 16]))
+        out.append(dict(N=N, K=int(rng.integers(1, 5)), C=int(rng.choice([1, 2, 3, 5, 8, 16, 17, 24, 32])), R=int(rng.choice([2, 3, 4, 5, 7, 9])),
+                        plan=str(rng.choice(["f64", "f64", "f32"])), x=str(rng.choice(["f64", "f64", "f32", "i16", "i32"])),
+                        lin=str(rng.choice(["frame", "stack", "padded"])), lout=str(rng.choice(["frame", "stack"])),
+                        filt=int(rng.choice([0, 0, 1, 2, 3])), seed=i))
+    return out
+
+
+@pytest.mark.parametrize("c", _random_source_cases(), ids=lambda c: "N%d-K%d-C%d-R%d-%s-%s-%s-%s-f%d" % (
+    c["N"], c["K"], c["C"], c["R"], c["plan"], c["x"], c["lin"], c["lout"], c["filt"]))
+def test_random_source_cases_against_the_oracle(c):
+    """Randomised sweep over what selects a path inside zmls_impulse_sources_device: single / multi-pass orders, one to four
+    stimuli, period counts either side of the shared-sum rule, sample types, layouts in and out, filter orders 0-3.
+    Every (stimulus, channel) response is held to the oracle (after scipy's lfilter when a filter is given)."""
+    NPT = {"f64": np.float64, "f32": np.float32, "i16": np.int16, "i32": np.int32}
+    N, K, C, R = c["N"], c["K"], c["C"], c["R"]
+    taps = [tuple(t) for t in TAPS[N][:K]]
+    plans = _plans(N, taps, c["plan"])
+    L = plans[0].L
+    x = _mixture(N, taps, R, C, seed=500 + c["seed"], dtype=NPT[c["x"]])
+    f, y = None, x.astype(np.float64)
+    if c["filt"]:
+        rng = np.random.default_rng(c["seed"])
+        B, A = rng.standard_normal(c["filt"] + 1), np.poly(0.7 * rng.uniform(-1, 1, c["filt"]))
+        f = IirFilter(B, A, device=0)
+        y = lfilter(B, A, y, axis=0)
+    if c["lin"] == "frame":
+        xm, rs, cs = np.ascontiguousarray(x), C, 1
+    elif c["lin"] == "stack":
+        xm, rs, cs = np.ascontiguousarray(x.T), 1, R * L
+    else:
+        xm = np.zeros((R * L, C + 3), dtype=x.dtype)
+        xm[:, :C] = x
+        rs, cs = C + 3, 1
+    group = Sources(plans)
+    group.reserve(R * L, C, iir=f)
+    npdt = plans[0].np_dtype
+    d_x = DeviceBuffer(xm.nbytes, 0).upload(xm)
+    d_h = DeviceBuffer(K * L * C * np.dtype(npdt).itemsize, 0)
+    ors, ocs = (C, 1) if c["lout"] == "frame" else (1, L)
+    group.impulse_device(d_x.ptr, _lib.dtype_code(x.dtype), R * L, C, rs, cs, d_h.ptr, L * C, ors, ocs, iir=f)
+    sync(0)
+    h = d_h.download((K, L, C) if c["lout"] == "frame" else (K, C, L), npdt)
+    h = h if c["lout"] == "frame" else h.transpose(0, 2, 1)
+    tol = 1e-12 if c["plan"] == "f64" else 2e-5
+    for k in range(K):
+        ref = c_oracle.sequence(N, taps[k])
+        for ch in sorted({0, C // 2, C - 1}):
+            assert rel_err(h[k, :, ch], oracle_ir(N, taps[k], np.ascontiguousarray(y[:, ch:ch + 1]), ref)) <= tol, (k, ch)
+    d_x.free()
+    d_h.free()
+    if f is not None:
+        f.close()
