@@ -40,3 +40,18 @@ def test_example_chain_matches_the_oracle_chain(N, fs, repeats):
     assert np.array_equal(freqs, f_want)
     lin, lin_want = 10 ** (mag / 20), 10 ** (m_want / 20)
     assert np.max(np.abs(lin - lin_want)) <= 1e-12 * np.max(lin_want)
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_of_the_abi():
+    """examples/c_api.c (C99, include/zmls.h only) built beforehand by build(): loop-back measurement through the host entry
+    points, unit impulse within 1e-12, the reference's too-short-capture assertion as an error code."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "_build", "c_api")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        exe = g.build_c_example()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c_api ok" in r.stdout, r.stdout + r.stderr
+    assert "one period only -> -1" in r.stdout

@@ -251,3 +251,17 @@ def test_audio_append_builds_the_multichannel_stimulus():
         a.append(Audio(fs=48000, initialdata=np.zeros((8, 1), dtype=np.float32)))
     with pytest.raises(AssertionError):
         a.append(np.zeros((8, 1)))
+
+
+def test_plain_c_program_compiles_against_the_product_header_and_fails_loudly_without_a_gpu(lib):
+    """include/zmls.h is C (C99, -pedantic -Werror), not only C++: examples/c_api.c uses nothing else. Without a GPU it
+    reports that and leaves with status 3 - no CPU path behind the ABI either."""
+    import __graft_entry__ as g
+    exe = g.build_c_example()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    n = ctypes.c_int()
+    lib.zmls_device_count(ctypes.byref(n))
+    if n.value > 0:
+        assert r.returncode == 0 and "c_api ok" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "no CPU path" in r.stdout, r.stdout + r.stderr
