@@ -102,8 +102,11 @@ __global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict
     __shared__ double tile[256 * kIirPitch];
     __shared__ double sc[256 * S];
     const int tid = threadIdx.x;
-    const int64_t chunk = blockIdx.x / n_cgrp;
-    const int64_t t0 = chunk * TT, c0 = (int64_t)(blockIdx.x % n_cgrp) * CC;
+    // frame-major tiles: the channel groups of one chunk are pieces of the same rows; renumbered so that they run on one XCD,
+    // next to each other in time (workgroups are dealt to the 8 XCDs in turn)
+    const uint32_t bid = (CC > 1 && gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int64_t chunk = bid / n_cgrp;
+    const int64_t t0 = chunk * TT, c0 = (int64_t)(bid % n_cgrp) * CC;
 
     constexpr int PER = TT * CC / 256;             // elements per thread in the coalesced load / store sweeps (32)
     if (in_dtype == ZMLS_F64 && t0 + TT <= n_rows && c0 + CC <= n_ch) {
@@ -375,8 +378,11 @@ __global__ void __launch_bounds__(256, (S <= 5 ? 2 : 1)) iir_period_kernel(const
     __shared__ double tile[256 * kIirPitch];
     __shared__ double sc[256 * S];
     const int tid = threadIdx.x;
-    const int64_t chunk = blockIdx.x / n_cgrp;
-    const int64_t j0 = L - (n_chunks - chunk) * TT, c0 = (int64_t)(blockIdx.x % n_cgrp) * CC;
+    // workgroups are dealt to the 8 XCDs in turn: renumber them so that the channel groups of one chunk - the pieces of the
+    // same capture rows - run on one XCD, next to each other in time
+    const uint32_t bid = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int64_t chunk = bid / n_cgrp;
+    const int64_t j0 = L - (n_chunks - chunk) * TT, c0 = (int64_t)(bid % n_cgrp) * CC;
     const bool interior = in_dtype == ZMLS_F64 && j0 >= 0 && c0 + CC <= n_ch;
     const int sb = tid / CC;
     const int64_t c = c0 + tid % CC;
