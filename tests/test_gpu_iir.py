@@ -85,6 +85,25 @@ def test_device_entry_point_in_place_and_workspace_error():
     assert ei.value.code == _lib.E_UNSUPPORTED
 
 
+def test_one_filter_object_on_a_long_narrow_then_a_shorter_wide_signal():
+    """The group arrays of the second-level scan are sized apart from the chunk arrays: a long one-channel signal needs
+    MORE chunk states and FEWER group states than a shorter signal of many channels (round-2 advisor finding: the second
+    call's group scan wrote past arrays sized by the first)."""
+    rng = np.random.default_rng(77)
+    B, A = stable_filter(2, rng)
+    f = IirFilter(B, A, device=0)
+    for shape in ((2_400_000, 1), (8704, 1000), (1_200_000, 2), (9000, 700)):
+        x = rng.standard_normal(shape)
+        want = scipy.signal.lfilter(B, A, x, axis=0)
+        assert rel_err(f.filter_host(x), want) <= TOL                          # frame-major: 512-frame chunks, 17+ of them
+    d = DeviceBuffer(8 * 8704 * 1200)
+    with pytest.raises(_lib.ZmlsError) as ei:                                  # wider than anything reserved: refused, not overrun
+        f.filter_device(d.ptr, _lib.ZMLS_F64, 8704, 1200, 1200, 1, d.ptr, 1200, 1)
+    assert ei.value.code == _lib.E_WORKSPACE
+    d.free()
+    f.close()
+
+
 def test_long_capture_like_the_headline_stimulus():
     """(R*L, 1) at N=20, R=3: 3.1 M samples, 384 chunks; de-emphasis of an emphasised MLS gives the MLS back."""
     N, R = 20, 3

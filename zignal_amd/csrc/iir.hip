@@ -574,6 +574,7 @@ struct zmls_iir {
     double *d_zc, *d_sin;      // zero-state end state / start state of every chunk
     double *d_zg, *d_sg;       // the same of every group of 256 chunks (1/256 of the above)
     size_t scratch_elems;      // of d_zc, d_sin each
+    size_t group_elems;        // of d_zg, d_sg each: not monotonic in scratch_elems (few long channels against many short ones)
     // the fused de-emphasis + impulse response path (zmls_iir_reserve_fused)
     long double A[zmls::kIirMaxS * zmls::kIirMaxS];   // state matrix, S x S (host)
     double *d_e, *d_E, *d_zi, *d_sum, *d_phi;          // chunk end states of every period, period end states, sum of start states, period sums, A^L
@@ -582,6 +583,33 @@ struct zmls_iir {
 };
 
 using namespace zmls;
+
+namespace zmls {
+namespace {
+// elements of the chunk arrays (d_zc, d_sin) and of the group arrays (d_zg, d_sg) a signal of this shape needs when its
+// chunks are tt frames long. The two are sized and checked apart: ceil(chunks / 256) * channels is not monotonic in
+// chunks * channels (a long one-channel signal needs more chunk states and FEWER group states than a shorter one of a
+// thousand channels).
+void iir_scratch_need(const zmls_iir *f, int64_t n_rows, int64_t n_ch, int64_t tt, size_t *need, size_t *need_g)
+{
+    const size_t chunks = (size_t)((n_rows + tt - 1) / tt);
+    *need = chunks * (size_t)n_ch * (size_t)f->S;
+    *need_g = chunks > (size_t)kIirSerialChunks ? ((chunks + kIirGroup - 1) / kIirGroup) * (size_t)n_ch * (size_t)f->S : 0;
+}
+int iir_scratch_check(const zmls_iir *f, int64_t n_rows, int64_t n_ch, int64_t tt)
+{
+    size_t need = 0, need_g = 0;
+    iir_scratch_need(f, n_rows, n_ch, tt, &need, &need_g);
+    if (need > f->scratch_elems || need_g > f->group_elems) {
+        set_error("filter scratch holds %zu chunk and %zu group states, %zu and %zu needed: call zmls_iir_reserve first", f->scratch_elems,
+                  f->group_elems, need, need_g);
+        return ZMLS_E_WORKSPACE;
+    }
+    return ZMLS_OK;
+}
+} // namespace
+} // namespace zmls
+
 
 // The capture swept once: periods 1..R-1 added up, the filter's state at every period boundary beside it; then the
 // filter over the one period of sums from the summed states. Leaves the filtered sums in the filter's own array.
@@ -606,6 +634,8 @@ int zmls::filtered_period_sums(zmls_plan *p, zmls_iir *f, const void *d_x, int i
         set_error("call zmls_iir_reserve_fused(filter, plan, n_rows, n_ch) first");
         return ZMLS_E_WORKSPACE;
     }
+    rc = iir_scratch_check(f, L, n_ch, tt);                    // the filter over the one period of sums
+    if (rc) return rc;
     // the sums keep the layout class of the capture: (L, n_ch) frames x channels, or n_ch runs of L frames
     const int64_t srs = tc ? 1 : n_ch, scs = tc ? L : 1;
 #define ZPER(SS) case SS: rc = tc ? launch_period_s<SS, 1>(f->d_f, d_x, in_dtype, L, R, n_ch, row_stride, ch_stride, f->d_e, f->d_E, f->d_phi, f->d_zi, f->d_sum, srs, scs, st) \
@@ -702,19 +732,24 @@ int zmls_iir_reserve(zmls_iir *f, int64_t n_rows, int64_t n_ch)
     ZDEVICE(f->device);
     int rc = ZMLS_OK;
     const int64_t tt = (256 / 16) * kIirSub;                                   // the shorter chunk (frame-major tiles)
-    const size_t need = (size_t)((n_rows + tt - 1) / tt) * (size_t)n_ch * (size_t)f->S;
-    if (need <= f->scratch_elems) return ZMLS_OK;
-    if (f->d_zc) { ZHIP(hipFree(f->d_zc)); f->d_zc = nullptr; }
-    if (f->d_sin) { ZHIP(hipFree(f->d_sin)); f->d_sin = nullptr; }
-    if (f->d_zg) { ZHIP(hipFree(f->d_zg)); f->d_zg = nullptr; }
-    if (f->d_sg) { ZHIP(hipFree(f->d_sg)); f->d_sg = nullptr; }
-    f->scratch_elems = 0;
-    const size_t need_g = (size_t)(((n_rows + tt - 1) / tt + kIirGroup - 1) / kIirGroup) * (size_t)n_ch * (size_t)f->S;
-    ZHIP(hipMalloc((void **)&f->d_zc, need * 8));
-    ZHIP(hipMalloc((void **)&f->d_sin, need * 8));
-    ZHIP(hipMalloc((void **)&f->d_zg, need_g * 8));
-    ZHIP(hipMalloc((void **)&f->d_sg, need_g * 8));
-    f->scratch_elems = need;
+    size_t need = 0, need_g = 0;
+    iir_scratch_need(f, n_rows, n_ch, tt, &need, &need_g);
+    if (need > f->scratch_elems) {
+        if (f->d_zc) { ZHIP(hipFree(f->d_zc)); f->d_zc = nullptr; }
+        if (f->d_sin) { ZHIP(hipFree(f->d_sin)); f->d_sin = nullptr; }
+        f->scratch_elems = 0;
+        ZHIP(hipMalloc((void **)&f->d_zc, need * 8));
+        ZHIP(hipMalloc((void **)&f->d_sin, need * 8));
+        f->scratch_elems = need;
+    }
+    if (need_g > f->group_elems) {
+        if (f->d_zg) { ZHIP(hipFree(f->d_zg)); f->d_zg = nullptr; }
+        if (f->d_sg) { ZHIP(hipFree(f->d_sg)); f->d_sg = nullptr; }
+        f->group_elems = 0;
+        ZHIP(hipMalloc((void **)&f->d_zg, need_g * 8));
+        ZHIP(hipMalloc((void **)&f->d_sg, need_g * 8));
+        f->group_elems = need_g;
+    }
     return ZMLS_OK;
 }
 
@@ -728,8 +763,8 @@ int zmls_iir_device(zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, 
     int rc = ZMLS_OK;
     const bool tc = row_stride == 1 && (n_ch == 1 || ch_stride != 1);
     const int64_t tt = (256 / (tc ? 1 : 16)) * kIirSub;
-    const size_t need = (size_t)((n_rows + tt - 1) / tt) * (size_t)n_ch * (size_t)f->S;
-    if (need > f->scratch_elems) { set_error("filter scratch holds %zu chunk states, %zu needed: call zmls_iir_reserve first", f->scratch_elems, need); return ZMLS_E_WORKSPACE; }
+    rc = iir_scratch_check(f, n_rows, n_ch, tt);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
 #define ZIIR(SS) case SS: return launch_iir_cc<SS>(tc, f->d_f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, f->d_zc, f->d_sin, f->d_zg, f->d_sg, d_y, out_row_stride, out_ch_stride, nullptr, st);
     switch (f->S) {
