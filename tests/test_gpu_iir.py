@@ -92,13 +92,13 @@ def test_one_filter_object_on_a_long_narrow_then_a_shorter_wide_signal():
     rng = np.random.default_rng(77)
     B, A = stable_filter(2, rng)
     f = IirFilter(B, A, device=0)
-    for shape in ((2_400_000, 1), (8704, 1000), (1_200_000, 2), (9000, 700)):
+    for shape in ((17_800_000, 1), (8704, 1000), (1_200_000, 2), (9000, 700)):     # 34766 chunk states, then 17000 with 1000 group states
         x = rng.standard_normal(shape)
         want = scipy.signal.lfilter(B, A, x, axis=0)
         assert rel_err(f.filter_host(x), want) <= TOL                          # frame-major: 512-frame chunks, 17+ of them
-    d = DeviceBuffer(8 * 8704 * 1200)
+    d = DeviceBuffer(8 * 8704 * 2400)
     with pytest.raises(_lib.ZmlsError) as ei:                                  # wider than anything reserved: refused, not overrun
-        f.filter_device(d.ptr, _lib.ZMLS_F64, 8704, 1200, 1200, 1, d.ptr, 1200, 1)
+        f.filter_device(d.ptr, _lib.ZMLS_F64, 8704, 2400, 2400, 1, d.ptr, 2400, 1)
     assert ei.value.code == _lib.E_WORKSPACE
     d.free()
     f.close()
