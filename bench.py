@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--reserve-channels", type=int, default=0, help="workspace for this many channels only (the batch then runs in channel chunks; tuning)")
     ap.add_argument("--plain-alloc", action="store_true", help="allocate the capture with one plain hipMalloc (no placement probing)")
     ap.add_argument("--tile", type=int, default=-1, help="force a tile configuration (tuning): 0 small, 1 big, 2 mid, 3 tall, +256 no XCD swizzle")
+    ap.add_argument("--resident", default="auto", help="cache-resident schedule (tuning): auto, off, or on[:MiB[:flags]]")
     ap.add_argument("--configs", default="auto", choices=["auto", "all", "none"],
                     help="the other BASELINE configs after the headline (N=1 only): auto = when the headline workload is the default one")
     ap.add_argument("--period-leg", default="auto", choices=["auto", "none"],
@@ -517,6 +518,9 @@ def main():
     placement = None
     if args.tile >= 0:
         plan.force_tile(args.tile)
+    if args.resident != "auto":
+        r = args.resident.split(":")
+        plan.set_resident({"off": 0, "on": 1}[r[0]], (int(r[1]) << 20) if len(r) > 1 else 0, int(r[2]) if len(r) > 2 else 0)
     comm = None
     if args.mode == "channel":
         seed, ch_first = SEED + 1000 * rank, 0

@@ -73,6 +73,14 @@ int zmls_plan_export_table(zmls_plan *p, int which, uint32_t *out);
  * pass on rows that are not scattered (tools/gather_order.py). The plan's responses are meaningless afterwards. */
 int zmls_plan_import_table(zmls_plan *p, int which, const uint32_t *in);
 
+/* Tuning / tests: the cache-resident schedule of zmls_impulse_device (csrc/api.hip::run_passes). Batches of one
+ * or two averaged periods run in chunks whose intermediate fits the 256 MiB Infinity Cache, with the intermediate's stores
+ * and loads on the default cache policy. mode -1: the library decides (default), 0: never, 1: whatever the period count.
+ * bytes: chunk size (0 = the built-in 256 MiB). flags: 1 = the in-place second pass of a three-pass order keeps its stores in
+ * the cache too, 2 = non-temporal loads of the resident intermediate. The results do not depend on any of it (same
+ * arithmetic, another launch order). No reference counterpart. */
+int zmls_plan_set_resident(zmls_plan *p, int mode, size_t bytes, int flags);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU test tier) */
 /* how a 2^N-point transform is split into LDS-resident passes: bits[i] for i < returned count */
 int zmls_host_pass_split(int N, int bits[4]);

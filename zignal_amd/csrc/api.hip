@@ -2,6 +2,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <atomic>
 #include <vector>
 #include "zmls_internal.h"
@@ -210,6 +211,7 @@ int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int
     p->device = device;
     p->force_cfg = -1;
     p->swizzle = 1;
+    p->resident_mode = -1;
     rc = build_plan(p);
     if (rc) { free_plan_buffers(p); free(p); return rc; }
     *out = p;
@@ -290,6 +292,15 @@ int zmls_plan_force_tile(zmls_plan *p, int cfg)
     p->swizzle = (cfg >= 0 && (cfg & 0x100)) ? 0 : 1;     // +256: switch the XCD-aware block mapping off (tuning)
     p->work_layout = (cfg >= 0 && (cfg & 0x400)) ? 1 : 0; // +1024: row-major workspace (tuning)
     p->force_cfg = cfg < 0 ? -1 : (cfg & 0xFF);
+    return ZMLS_OK;
+}
+
+int zmls_plan_set_resident(zmls_plan *p, int mode, size_t bytes, int flags)
+{
+    if (!p || mode < -1 || mode > 1) { set_error("cache-resident schedule: mode must be -1 (auto), 0 (off) or 1 (on)"); return ZMLS_E_ARG; }
+    p->resident_mode = mode;
+    p->resident_bytes = bytes;
+    p->resident_flags = flags;
     return ZMLS_OK;
 }
 
@@ -467,7 +478,7 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
         return ZMLS_OK;
     }
 
-    const int64_t cap = (int64_t)(work_bytes / slab_bytes(p, cfg));
+    int64_t cap = (int64_t)(work_bytes / slab_bytes(p, cfg));
     if (cap < 1) {
         if (own_work) set_error("plan workspace (%zu bytes) holds no channel slab (%zu bytes each): call zmls_plan_reserve first", work_bytes, slab_bytes(p, cfg));
         else set_error("order %d needs %zu bytes of workspace for one channel slab; the caller's workspace holds %zu", p->N, slab_bytes(p, cfg), work_bytes);
@@ -476,27 +487,80 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
     a.work = work;
     a.scatter = p->d_scatter_perm[cfg];
     if (!a.scatter) { set_error("tile configuration %d has not been prepared for this plan", cfg); return ZMLS_E_UNSUPPORTED; }
+
+    // ---- the cache-resident schedule (round 3). With one or two averaged periods every pass moves the whole batch through
+    // HBM, so the bytes moved are two or three times the algorithmic ones. The 256 MiB Infinity Cache takes one of those
+    // round trips away when the batch runs in chunks whose intermediate fits it and the intermediate's stores and loads
+    // use the default cache policy while the capture and the responses stream past non-temporally (tools/ic_probe.hip:
+    // the two-pass shape moves 3.3-3.4 TB/s of capture + response bytes in chunks of 96-256 MiB against 2.2-2.3 TB/s
+    // beyond 512 MiB). Two-pass orders: chunks of channel slabs, both passes per chunk. Three-pass orders: passes 1 and 2
+    // are closed under the low K0+K1 bits, so they run chunk by chunk over ranges of the top bits (contiguous macro tiles
+    // in both), the second in place; the third pass then runs over everything from HBM. With many periods the capture
+    // stream is what counts and the non-temporal pair of round 2 stays (fwht_kernels.inc).
+    const size_t sbytes = slab_bytes(p, cfg);
+    const size_t budget = p->resident_bytes ? p->resident_bytes : kResidentBytes;
+    const bool want_resident = !gather_pass_only && p->work_layout == 0 &&
+                               (p->resident_mode > 0 || (p->resident_mode < 0 && periods <= kResidentMaxPeriods));
+    const bool resident2 = want_resident && npass == 2 && sbytes <= budget;
+    const bool resident3 = want_resident && npass == 3 && pass_bits[1] >= log2_tiles(pass_bits[0], tc) && pass_bits[0] >= log2_tiles(pass_bits[1], tc);
+    if (resident2 && (int64_t)(budget / sbytes) < cap) cap = (int64_t)(budget / sbytes);
+    const uint64_t U = 1ull << tc.lu;
+    auto swizzle_of = [&](int i, uint32_t n_macro, uint32_t ns) -> uint32_t {
+        if (cfg == CFG_BIG || p->swizzle == 0) return 0;
+        if (i == 0 || p->work_layout) return (n_macro % 8 == 0) ? ns : 0;
+        return (((uint64_t)n_macro * ns) % 16 == 0) ? 2 : 0;
+    };
     for (int64_t s0 = 0; s0 < n_slabs; s0 += cap) {
         const uint32_t ns = (uint32_t)((n_slabs - s0 < cap) ? n_slabs - s0 : cap);
         a.ch_first = s0 * CS;
         a.n_slab_groups = ns;
-        const uint64_t U = 1ull << tc.lu;
+        a.work = work;
+        a.macro_first = 0;
         a.slab_fastest = p->work_layout;
         a.work_slab_stride = p->work_layout ? U : work_rows_total(p->N) * U;
         a.work_row_stride = p->work_layout ? (uint64_t)ns * U : U;
-        int b = 0;
-        for (int i = 0; i < (gather_pass_only ? 1 : npass); ++i) {
+        int b = 0, first_pass = 0;
+        if (resident3) {
+            const int K0 = pass_bits[0], K1 = pass_bits[1], K2 = pass_bits[2];
+            const int LT0 = log2_tiles(K0, tc), LT1 = log2_tiles(K1, tc);
+            const size_t per_top = ((size_t)1 << (K0 + K1)) * (size_t)(U * kVecBytes);       // bytes of one slab's rows under one value of the top bits
+            const uint32_t sub = (uint32_t)std::min<uint64_t>(ns, std::max<uint64_t>(1, budget / per_top));
+            const uint32_t tops = (uint32_t)std::min<uint64_t>(1ull << K2, std::max<uint64_t>(1, budget / (per_top * sub)));
+            if (ev) ZHIP(hipEventRecord(ev[0], st));
+            for (uint32_t ss = 0; ss < ns; ss += sub) {
+                const uint32_t nsub = std::min(sub, ns - ss);
+                a.ch_first = (s0 + ss) * CS;
+                a.n_slab_groups = nsub;
+                a.work = (char *)work + (size_t)ss * a.work_slab_stride * kVecBytes;
+                for (uint32_t t0 = 0; t0 < (1u << K2); t0 += tops) {
+                    const uint32_t nt = std::min(tops, (1u << K2) - t0);
+                    a.b = 0; a.macro_first = t0 << (K1 - LT0); a.n_macro = nt << (K1 - LT0);
+                    a.swz_group = swizzle_of(0, a.n_macro, nsub);
+                    a.work_keep_ld = 0; a.work_keep_st = 1;
+                    rc = launch(cfg, K0, vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM, OUT_WORK, a, st);
+                    if (rc) return rc;
+                    a.b = K0; a.macro_first = t0 << (K0 - LT1); a.n_macro = nt << (K0 - LT1);
+                    a.swz_group = swizzle_of(1, a.n_macro, nsub);
+                    a.work_keep_ld = 1; a.work_keep_st = p->resident_flags & 1;      // on its way to HBM: streams unless told otherwise (tuning)
+                    rc = launch(cfg, K1, IN_WORK, OUT_WORK, a, st);
+                    if (rc) return rc;
+                }
+            }
+            if (ev) ZHIP(hipEventRecord(ev[1], st));
+            a.ch_first = s0 * CS; a.n_slab_groups = ns; a.work = work; a.macro_first = 0;
+            b = K0 + K1;
+            first_pass = 2;
+        }
+        for (int i = first_pass; i < (gather_pass_only ? 1 : npass); ++i) {
             const int K = pass_bits[i];
             const int LT = log2_tiles(K, tc);
             a.b = b;
             a.n_macro = (uint32_t)(1u << (p->N - K - LT));
-            const uint64_t total = (uint64_t)a.n_macro * ns;
             const int inm = (i == 0) ? (vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM) : IN_WORK;
             const int outm = (i == npass - 1) ? (vec_out ? OUT_SCATTER_VEC : OUT_SCATTER_ELEM) : OUT_WORK;
-            if (cfg == CFG_BIG) a.swz_group = 0;
-            else if (p->swizzle == 0) a.swz_group = 0;
-            else if (i == 0 || p->work_layout) a.swz_group = (a.n_macro % 8 == 0) ? ns : 0;
-            else a.swz_group = (total % 16 == 0) ? 2 : 0;
+            a.swz_group = swizzle_of(i, a.n_macro, ns);
+            a.work_keep_st = resident2 ? 1 : 0;
+            a.work_keep_ld = (resident2 && !(p->resident_flags & 2)) ? 1 : 0;
             if (ev) ZHIP(hipEventRecord(ev[2 * i], st));
             rc = launch(cfg, K, inm, outm, a, st);
             if (rc) return rc;
@@ -505,6 +569,7 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
         }
         if (ev)
             for (int i = 0; i < (gather_pass_only ? 1 : npass); ++i) {
+                if (resident3 && i == 1) continue;          // passes 1 and 2 ran chunk by chunk: their time is under pass 1
                 float ms = 0.f;
                 ZHIP(hipEventSynchronize(ev[2 * i + 1]));
                 ZHIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));

@@ -16,6 +16,10 @@ constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr int kMaxTransformOrder = 30;
 constexpr int kMaxSequenceOrder = 32;
 constexpr int kSynthTaps = 16;
+// cache-resident schedule (api.hip::run_passes): chunk size that keeps the intermediate in the 256 MiB Infinity Cache, and
+// the largest period count it is used for by default (beyond it the capture stream dominates and everything streams)
+constexpr size_t kResidentBytes = (size_t)256 << 20;
+constexpr int kResidentMaxPeriods = 2;
 
 // tile configurations (geometry.h). CFG_SMALL is the general one (any channel count, any strides,
 // single-pass orders); CFG_BIG is the streaming one for wide, vector-aligned channel blocks.
@@ -75,6 +79,8 @@ struct PassArgs {
     int slab_fastest;         // later passes: consecutive blocks are the slabs of one tile (else the tiles of one slab)
     void *work;               // row d of the transform of slab s at vector  s*work_slab_stride + work_row(d)*work_row_stride
     uint64_t work_slab_stride, work_row_stride;   // in 16-byte vectors: slab-major [slab][row][2^LU] or row-major [row][slab][2^LU]
+    int work_keep_ld, work_keep_st;   // 1: default cache policy for the intermediate's loads / stores (cache-resident schedule), 0: non-temporal
+    uint32_t macro_first;     // first macro tile of this launch (row-range chunks of the cache-resident schedule)
     // gather-in
     const void *x;
     int in_dtype;
@@ -197,4 +203,7 @@ struct zmls_plan {
     int swizzle;                  // XCD-aware block mapping on/off (tuning)
     int in_scale_log2;            // captures are raw integers with full scale 2^k: responses come out divided by 2^k
     int work_layout;              // 0: workspace slab-major, 1: row-major with slab-fastest block order in every pass
+    int resident_mode;            // cache-resident schedule: -1 auto (few periods), 0 off, 1 on
+    size_t resident_bytes;        // its chunk size (0: kResidentBytes)
+    int resident_flags;           // tuning: 1 = pass 2 of three keeps its stores in the cache too, 2 = non-temporal loads of the resident intermediate
 };

@@ -89,6 +89,10 @@ class Plan:
         """-1 auto, 0 small, 1 big, 2 mid, 3 tall tile (tests / tuning)"""
         L.check(L.lib().zmls_plan_force_tile(self._h, int(cfg)))
 
+    def set_resident(self, mode=-1, nbytes=0, flags=0):
+        """cache-resident schedule (tests / tuning): -1 the library decides, 0 off, 1 on; chunk bytes (0 = built-in); flags"""
+        L.check(L.lib().zmls_plan_set_resident(self._h, int(mode), int(nbytes), int(flags)))
+
     def reserve(self, n_ch, staging=False):
         """Workspace for n_ch channels per launch; staging=True also reserves the layout-adapter arrays for captures
         that are not aligned (frames, channels) data of the plan's dtype (zmls_plan_reserve_staging)."""
