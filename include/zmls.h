@@ -55,9 +55,14 @@ int zmls_device_count(int *n);
  * work the reference redoes on every call: the per-bit LFSR loop of
  * generator_bit/generator_chunk (mls.py:91-128) and the regeneration of the
  * stimulus inside xcorr_circular (mls.py:207).
- * taps: 1-indexed feedback delays as in zignal/measure/mlstaps.py:16-17; max(taps) must be N.
+ * taps: 1-indexed feedback delays as in zignal/measure/mlstaps.py:16-17. Like the reference, which checks nothing
+ * (mls.py:64-68), every tap set its register can index is accepted: taps 1..N in any combination, maximum-length or
+ * not, with or without N, and N+1..2N, which Python's negative deque index (mls.py:107) maps onto taps 1..N; anything
+ * else is the reference's IndexError (ZMLS_E_ARG here). The SEQUENCE entry points work for all of them (and for
+ * orders 31, 32). The impulse-response entry points need a maximum-length sequence of order <= 30 (zmls_plan_kind says
+ * which a plan is) and return ZMLS_E_UNSUPPORTED otherwise.
  * dtype: arithmetic type of the impulse-response path, ZMLS_F64 (reference) or ZMLS_F32.
- * device: HIP device ordinal. 2 <= N <= 30. */
+ * device: HIP device ordinal. 2 <= N <= 32. */
 int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int dtype, int device);
 int zmls_plan_destroy(zmls_plan *p);
 /* Make sure the workspace can hold `n_ch` channels in one go (allocates; call outside timed/captured regions). */
@@ -84,6 +89,9 @@ int zmls_plan_info(const zmls_plan *p, int64_t info[16]);
  * with every rounding on the path). k = 0 (default): samples are taken at face value, as numpy does when the
  * reference is handed an integer array. State of the plan; 0 <= k <= 63. */
 int zmls_plan_set_input_scale_log2(zmls_plan *p, int k);
+/* *maximal: 1 when the register's period is 2^N - 1; *transform: 1 when the impulse-response entry points work on this
+ * plan (maximal and N <= 30). Either pointer may be null. */
+int zmls_plan_kind(const zmls_plan *p, int *maximal, int *transform);
 
 /* ---- sequence: replaces generator_bit / generator_chunk / generator_samples /
  * get_full_sequence (mls.py:91-167). */
@@ -91,6 +99,11 @@ int zmls_plan_set_input_scale_log2(zmls_plan *p, int k);
  * mls.py:117-128), LSB-first packed, unused bits of the last byte zero;
  * nbits <= 2^N + 32. */
 int zmls_sequence_bits(zmls_plan *p, uint8_t *out_packed, int64_t nbits);
+/* `nbits` bits of the same endless generator from bit `start` on (generator_bit / generator_chunk keep their register
+ * running for as long as they are asked, mls.py:104-128): the register's state at `start` is found by jump-ahead, the
+ * bits are generated on the device. A maximum-length register repeats after L bits; any other runs on as the
+ * reference's does. Same packing; nbits <= 2^31 per call. */
+int zmls_sequence_bits_from(zmls_plan *p, uint64_t start, uint8_t *out_packed, int64_t nbits);
 /* repeats*L samples, bit 0 -> +1.0, bit 1 -> -1.0 (mls.py:150), host buffer */
 int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats);
 /* same on the device: d_out holds repeats*L elements of `dtype` (F64/F32), element stride `stride` */

@@ -33,8 +33,10 @@ static int lfsr_init(lfsr_t *r, int N, const int32_t *taps, int ntaps)
     r->N = N;
     r->ntaps = ntaps;
     for (int i = 0; i < ntaps; i++) {
-        if (taps[i] < 1 || taps[i] > N) return -1;
-        r->taps[i] = taps[i];
+        /* cells[N - tap]: a tap beyond N makes the index negative, which the reference's deque counts from the newest
+         * cell (mls.py:107): tap N+k reads the cell tap k reads. Tap 0 and taps beyond 2N are its IndexError. */
+        if (taps[i] < 1 || taps[i] > 2 * N) return -1;
+        r->taps[i] = taps[i] > N ? taps[i] - N : taps[i];
     }
     memset(r->cells, 0, sizeof r->cells);
     r->cells[N - 1] = 1;
@@ -82,8 +84,8 @@ int mls_oracle_bits_packed_word(int N, const int32_t *taps, int ntaps, uint8_t *
     if (N < 1 || N > 64 || ntaps < 1 || ntaps > 64) return -1;
     uint64_t mask = 0, reg = 1ull << (N - 1);
     for (int i = 0; i < ntaps; i++) {
-        if (taps[i] < 1 || taps[i] > N) return -1;
-        mask ^= 1ull << (N - taps[i]);          /* a tap listed twice cancels, as it does in the XOR loop */
+        if (taps[i] < 1 || taps[i] > 2 * N) return -1;
+        mask ^= 1ull << (N - (taps[i] > N ? taps[i] - N : taps[i]));   /* a tap listed twice cancels, as it does in the XOR loop */
     }
     memset(out, 0, (size_t)((nbits + 7) / 8));
     for (int64_t i = 0; i < nbits; i++) {

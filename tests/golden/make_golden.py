@@ -123,6 +123,47 @@ def dump_seq_prefix():
     write_json("seq_prefix.json", {"prefixes": out})
 
 
+def dump_seq_any():
+    """Tap sets that are NOT in the reference's table but that its generator accepts all the same (it checks nothing,
+    mls.py:64-68): not primitive, without N, a single tap, a tap listed twice, and taps N+1..2N, which the negative deque
+    index at mls.py:107 maps onto 1..N. For each: the first L bits as get_full_sequence hands them out, and 3L+17 bits
+    of generator_chunk, whose register keeps running (no period L to wrap at). Plus the taps its register cannot index."""
+    sets = [(8, (8, 4)), (6, (6, 3)), (5, (5, 3, 2)), (8, (7, 3)), (10, (9, 4, 2)), (6, (12, 7)), (7, (14,)), (5, (5, 3, 3, 2)),
+            (4, (4,)), (9, (3,)), (12, (12, 11, 10, 2)), (16, (16, 8)), (16, (15, 1)), (3, (1,)), (11, (22, 13)), (18, (18, 9))]
+    out = []
+    for N, taps in sets:
+        m = _MLS_base(N, tuple(taps))
+        s = m.get_full_sequence(repeats=2)
+        assert s.shape == (2 * m.L, 1) and np.array_equal(s[:m.L], s[m.L:])
+        first = ((1.0 - s[:m.L, 0]) / 2.0).astype(np.uint8)
+        n_run = 3 * m.L + 17
+        run = next(m.generator_chunk(n_run))[:, 0].astype(np.uint8)
+        assert np.array_equal(run[:m.L], first)
+        gb = m.generator_bit()
+        assert [next(gb) for _ in range(min(n_run, 4000))] == [int(v) for v in run[:4000]]
+        out.append({"N": N, "taps": list(taps), "ones": int(first.sum()), "sha256": inputs.digest(np.packbits(first, bitorder="little")),
+                    "first64": "".join(str(int(b)) for b in first[:64]),
+                    "run_bits": n_run, "run_ones": int(run.sum()), "run_sha256": inputs.digest(np.packbits(run, bitorder="little")),
+                    "wraps_at_L": bool(np.array_equal(run[m.L:2 * m.L], first))})
+        print("seq any N=%d taps=%s ones=%d wraps=%s" % (N, taps, out[-1]["ones"], out[-1]["wraps_at_L"]), flush=True)
+    errors = []
+    for N, taps in [(5, (0,)), (5, (5, 11)), (6, (6, -1)), (4, (4, 9))]:
+        m = _MLS_base(N, tuple(taps))                    # the constructor accepts them
+        try:
+            next(m.generator_bit())
+            raised = None
+        except Exception as e:  # noqa: BLE001
+            raised = type(e).__name__
+        try:
+            m.get_full_sequence(1)
+            raised_full = None
+        except Exception as e:  # noqa: BLE001
+            raised_full = type(e).__name__
+        errors.append({"N": N, "taps": list(taps), "generator_bit": raised, "get_full_sequence": raised_full})
+        print("seq any error N=%d taps=%s -> %s / %s" % (N, taps, raised, raised_full), flush=True)
+    write_json("seq_any.json", {"sets": out, "errors": errors})
+
+
 # --------------------------------------------------------------------------- IR goldens
 def ref_impulse(N, taps, x):
     m = _MLS_base(N, tuple(taps))
@@ -370,7 +411,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     steps = {"taps": dump_taps, "errors": dump_errors, "api": dump_api, "fft": dump_fft,
-             "seq": lambda: dump_seq_kats(a.quick), "prefix": dump_seq_prefix, "simple_short": dump_simple_short, "multi": dump_multi_source, "ir": lambda: dump_ir(a.quick)}
+             "seq": lambda: dump_seq_kats(a.quick), "prefix": dump_seq_prefix, "seq_any": dump_seq_any, "simple_short": dump_simple_short, "multi": dump_multi_source, "ir": lambda: dump_ir(a.quick)}
     for name, fn in steps.items():
         if a.only and name not in a.only.split(","):
             continue

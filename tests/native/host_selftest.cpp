@@ -57,9 +57,21 @@ int main()
             CHECK(got == window_after(s.N, s.taps, s.nt, steps));
         }
     uint32_t st = 0;
-    const int32_t bad[2] = {5, 3};
-    CHECK(zmls_host_lfsr_state(4, bad, 2, 0, &st) == ZMLS_E_ARG);          // tap beyond N
+    const int32_t bad[2] = {9, 3}, zero[1] = {0}, alias[2] = {5, 3};
+    CHECK(zmls_host_lfsr_state(4, bad, 2, 0, &st) == ZMLS_E_ARG);          // tap beyond 2N: the reference's IndexError
+    CHECK(zmls_host_lfsr_state(4, zero, 1, 0, &st) == ZMLS_E_ARG);
     CHECK(zmls_host_lfsr_state(33, bad, 2, 0, &st) == ZMLS_E_ARG);
+    // taps N+1..2N read the cell of tap t-N (Python's negative deque index, mls.py:107); taps without N, non-primitive sets
+    // and single taps run too (the reference checks nothing)
+    const struct { int N; int32_t taps[4]; int nt; int32_t same[4]; } odd[] = {{4, {5, 3}, 2, {1, 3}}, {6, {12, 7}, 2, {6, 1}}, {8, {8, 4}, 2, {8, 4}},
+                                                                              {9, {3, 3}, 1, {3, 3}}, {7, {14, 14}, 1, {7, 7}}};
+    for (const auto &s : odd)
+        for (uint64_t steps : {0ull, 1ull, 5ull, 64ull, 1000ull, 70001ull}) {
+            uint32_t got = 0;
+            CHECK(zmls_host_lfsr_state(s.N, s.taps, s.nt, steps, &got) == 0);
+            CHECK(got == window_after(s.N, s.same, s.nt, steps));
+        }
+    (void)alias;
     // capture placement search on simulated machines: every buffer it takes is given back but the one it returns
     const float ms[6] = {14.5f, 13.5f, 12.6f, 13.4f, 12.61f, 15.0f};
     for (int max_live = 0; max_live <= 5; ++max_live)

@@ -158,11 +158,87 @@ def test_permutation_tables(N, taps):
     assert np.array_equal(par.astype(np.uint32), bits[(jj - mm) % L])
 
 
-def test_non_maximal_taps_are_rejected_loudly():
+def test_non_maximal_taps_generate_the_sequence_and_refuse_the_transform():
+    """x^8 + x^4 + 1 is not primitive: the reference generates its (short-period) sequence all the same, and so does the
+    plan; only the TRANSFORM - whose Hadamard identity needs a maximum-length sequence - is refused, loudly."""
     from zignal_amd import _lib
+    from zignal_amd.device import Plan
+    p = Plan(8, (8, 4), device=0)
+    assert p.kind() == (False, False)
+    assert p.sequence(2).shape == (2 * 255, 1)
+    x = np.zeros((2 * 255, 1))
     with pytest.raises(_lib.ZmlsError) as ei:
-        plan(8, (8, 4))          # x^8 + x^4 + 1 is not primitive
+        p.impulse_host(x)
     assert ei.value.code == _lib.E_UNSUPPORTED and "maximum-length" in str(ei.value)
+    with pytest.raises(_lib.ZmlsError) as ei:
+        p.reserve(4)
+    assert ei.value.code == _lib.E_UNSUPPORTED
+    p.close()
+    q = Plan(8, TAPS[8][0], device=0)
+    assert q.kind() == (True, True)
+    q.close()
+
+
+SEQ_ANY = load_json("seq_any.json")
+
+
+@pytest.mark.parametrize("kat", SEQ_ANY["sets"], ids=lambda k: "N%d-%s" % (k["N"], "_".join(map(str, k["taps"]))))
+def test_tap_sets_outside_the_table_bit_exact_against_the_reference(kat):
+    """rows a3-a6 for every tap set the reference accepts (it validates nothing, mls.py:64-68, 101-108): fixtures captured
+    from the real reference (tests/golden/make_golden.py --only seq_any) - the first L bits get_full_sequence tiles, and
+    3L+17 bits of generator_chunk's register, which runs on without wrapping at L when it is not maximum-length."""
+    from zignal_amd.measure.mls import _MLS_base
+    N, taps, L = kat["N"], tuple(kat["taps"]), (1 << kat["N"]) - 1
+    m = _MLS_base(N, taps)
+    s = m.get_full_sequence(2)
+    assert s.shape == (2 * L, 1) and s.dtype == np.float64 and np.array_equal(s[:L], s[L:])
+    first = ((1.0 - s[:L, 0]) / 2).astype(np.uint8)
+    assert inputs.digest(np.packbits(first, bitorder="little")) == kat["sha256"] and int(first.sum()) == kat["ones"]
+    assert "".join(map(str, first[:64])) == kat["first64"]
+    run = next(m.generator_chunk(kat["run_bits"]))
+    assert run.shape == (kat["run_bits"], 1) and run.dtype == np.int64
+    assert inputs.digest(np.packbits(run[:, 0].astype(np.uint8), bitorder="little")) == kat["run_sha256"]
+    # chunks continue one another, whatever their size, and generator_bit / generator_samples hand out the same stream
+    g = m.generator_chunk(1000)
+    pieces = np.concatenate([next(g)[:, 0] for _ in range(-(-kat["run_bits"] // 1000))])[:kat["run_bits"]]
+    assert np.array_equal(pieces, run[:, 0])
+    gb = m.generator_bit()
+    assert [next(gb) for _ in range(min(3000, kat["run_bits"]))] == run[:3000, 0].tolist()
+    gs = m.generator_samples(777)
+    assert np.array_equal(next(gs)[:, 0], 1.0 - 2.0 * run[:777, 0]) or kat["run_bits"] < 777
+    # far along the stream: the jump-ahead start state against the C oracle's bit-serial register
+    p = m._plan()
+    if not kat["wraps_at_L"] or kat["ones"] != 1 << (N - 1):
+        assert p.kind() == (False, False)
+    start = 5 * L + 12345
+    want = c_oracle.bits(N, list(taps), start + 4096)[start:]
+    assert np.array_equal(p.bits_from(start, 4096), want)
+
+
+def test_taps_the_register_cannot_index_raise_index_error_like_the_reference():
+    from zignal_amd.measure.mls import _MLS_base
+    for e in SEQ_ANY["errors"]:
+        m = _MLS_base(e["N"], tuple(e["taps"]))                  # the constructor accepts them (mls.py:64-68)
+        with pytest.raises(IndexError):
+            next(m.generator_bit())
+        with pytest.raises(IndexError):
+            m.get_full_sequence(1)
+
+
+def test_bits_from_far_positions_on_maximal_and_other_registers():
+    from zignal_amd.device import Plan
+    for N, taps in ((16, TAPS[16][0]), (16, (16, 8)), (9, (3,)), (20, TAPS[20][0])):
+        p = Plan(N, taps, device=0)
+        for start in (0, 1, (1 << N) - 2, (1 << N) - 1, 3 * (1 << N) + 5, (1 << 33) + 7, (1 << 45) + 123):
+            if start < (1 << 24):
+                want = c_oracle.bits(N, list(taps), start + 2000)[start:]
+            elif p.kind()[0]:
+                pos = start % ((1 << N) - 1)
+                want = c_oracle.bits(N, list(taps), pos + 2000)[pos:]
+            else:
+                continue
+            assert np.array_equal(p.bits_from(start, 2000), want), (N, taps, start)
+        p.close()
 
 
 def test_every_tap_set_of_the_reference_table():

@@ -138,12 +138,20 @@ def test_jump_ahead_matches_bit_serial_oracle(lib, N, taps):
 def test_bad_plan_arguments_without_gpu(lib):
     h = ctypes.c_void_p()
     arr, n = _lib.taps_array((5, 3))
-    # order out of range / tap out of range / register length not among the taps / bad dtype
+    # order out of range / bad dtype
     assert lib.zmls_plan_create(ctypes.byref(h), 1, arr, n, 0, 0) == _lib.E_ARG
-    assert lib.zmls_plan_create(ctypes.byref(h), 31, arr, n, 0, 0) == _lib.E_ARG
-    assert lib.zmls_plan_create(ctypes.byref(h), 4, arr, n, 0, 0) == _lib.E_ARG
-    arr2, n2 = _lib.taps_array((4, 3))
-    assert lib.zmls_plan_create(ctypes.byref(h), 5, arr2, n2, 0, 0) == _lib.E_ARG
+    assert lib.zmls_plan_create(ctypes.byref(h), 33, arr, n, 0, 0) == _lib.E_ARG
+    # taps the reference's register cannot index (its IndexError, mls.py:107): 0, negative, beyond 2N
+    for N, bad in ((5, (0,)), (5, (5, 11)), (6, (6, -1)), (4, (4, 9))):
+        arr2, n2 = _lib.taps_array(bad)
+        assert lib.zmls_plan_create(ctypes.byref(h), N, arr2, n2, 0, 0) == _lib.E_ARG
+        assert "deque index out of range" in _lib.last_error()
+    # everything else is a tap set the reference generates a sequence for - without N, not primitive, N+1..2N - and gets
+    # as far as the device (none in this tier)
+    if _lib.device_count() == 0:
+        for N, ok in ((4, (5, 3)), (5, (4, 3)), (8, (8, 4)), (6, (12, 7))):
+            arr2, n2 = _lib.taps_array(ok)
+            assert lib.zmls_plan_create(ctypes.byref(h), N, arr2, n2, 0, 0) == _lib.E_NODEVICE
     assert lib.zmls_plan_create(ctypes.byref(h), 5, arr, n, 7, 0) == _lib.E_ARG
     assert "dtype" in _lib.last_error()
 

@@ -80,6 +80,37 @@ def test_word_register_oracle_sequence_kat(kat):
     assert np.array_equal(c_oracle.bits_packed_word(kat["N"], kat["taps"], n), c_oracle.bits_packed(kat["N"], kat["taps"], n))
 
 
+SEQ_ANY = load_json("seq_any.json")
+
+
+@pytest.mark.parametrize("kat", SEQ_ANY["sets"], ids=lambda k: "N%d-%s" % (k["N"], "_".join(map(str, k["taps"]))))
+def test_oracles_on_tap_sets_outside_the_table(kat):
+    """Taps the reference accepts without being in its table (not primitive, without N, N+1..2N through the negative
+    deque index, a tap twice): the first L bits and 3L+17 bits of the running register, from all three restatements."""
+    N, taps, L = kat["N"], tuple(kat["taps"]), (1 << kat["N"]) - 1
+    first = np.packbits(((1.0 - mls_oracle.full_sequence(N, taps)[:, 0]) / 2).astype(np.uint8), bitorder="little")
+    assert inputs.digest(first) == kat["sha256"]
+    run = next(mls_oracle.chunk_stream(N, taps, kat["run_bits"]))[:, 0].astype(np.uint8) if N <= 12 else None
+    for fn in (c_oracle.bits_packed, c_oracle.bits_packed_word):
+        assert inputs.digest(fn(N, list(taps), L)) == kat["sha256"], fn.__name__
+        packed = fn(N, list(taps), kat["run_bits"])
+        assert inputs.digest(packed) == kat["run_sha256"], fn.__name__
+        bits = np.unpackbits(packed, bitorder="little")[:kat["run_bits"]]
+        assert int(bits.sum()) == kat["run_ones"] and int(bits[:L].sum()) == kat["ones"]
+        assert bool(np.array_equal(bits[L:2 * L], bits[:L])) == kat["wraps_at_L"]
+        if run is not None:
+            assert np.array_equal(bits, run)
+
+
+def test_oracles_refuse_taps_the_register_cannot_index():
+    for e in SEQ_ANY["errors"]:
+        assert e["generator_bit"] == e["get_full_sequence"] == "IndexError"
+        with pytest.raises(IndexError):
+            next(mls_oracle.bit_stream(e["N"], tuple(e["taps"])))
+        with pytest.raises(Exception):
+            c_oracle.bits_packed(e["N"], e["taps"], 8)
+
+
 def test_c_oracle_matches_python_oracle_samples():
     for N, taps in ((5, (5, 4, 3, 2)), (9, (9, 5)), (12, (12, 11, 10, 4))):
         a = mls_oracle.full_sequence(N, taps, 3)

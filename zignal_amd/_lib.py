@@ -38,6 +38,8 @@ SIGNATURES = {
     "zmls_plan_set_input_scale_log2": [c_vp, c_int],
     "zmls_plan_info": [c_vp, ctypes.POINTER(c_i64)],
     "zmls_sequence_bits": [c_vp, c_vp, c_i64],
+    "zmls_sequence_bits_from": [c_vp, c_u64, c_vp, c_i64],
+    "zmls_plan_kind": [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "zmls_sequence_f64": [c_vp, c_vp, c_i64],
     "zmls_sequence_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_vp],
     "zmls_impulse_device": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],

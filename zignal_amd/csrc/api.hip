@@ -91,6 +91,7 @@ void free_plan_buffers(zmls_plan *p)
         if (p->d_scatter_perm[c]) (void)hipFree(p->d_scatter_perm[c]);
     if (p->d_jt) (void)hipFree(p->d_jt);
     if (p->d_work) (void)hipFree(p->d_work);
+    if (p->aux_stream) { (void)hipStreamDestroy(p->aux_stream); (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join); }
     for (int i = 0; i < 2; ++i) {
         if (p->d_stage[i]) (void)hipFree(p->d_stage[i]);
         if (p->d_host_call[i]) (void)hipFree(p->d_host_call[i]);
@@ -120,11 +121,15 @@ int build_plan(zmls_plan *p)
     // period boundary; rounded up to whole threads of the generator
     p->n_words = ((n + 64 + 1023) / 1024) * 32;
     ZHIP(hipMalloc((void **)&p->d_bits, p->n_words * 4));
-    if (p->N > kMaxTransformOrder) {
-        // orders 31 and 32: the bit sequence only (zmls_internal.h::kMaxTransformOrder). Without the tables, whose
-        // completeness is the proof elsewhere, the period is checked with powers of the state matrix on the host.
-        if (!period_is_maximal(p->N, jt)) { set_error("taps do not generate a maximum-length sequence of order %d", p->N); return ZMLS_E_UNSUPPORTED; }
-        int rc = launch_lfsr_tables(p->N, p->G, p->s0, p->d_jt, p->d_bits, p->n_words, nullptr, nullptr, 0);
+    // Is the register maximum-length? The reference does not ask (mls.py:64-68, 101-108: any taps generate a sequence),
+    // so the BITS are generated either way; the transform needs the Hadamard identity of a maximal sequence and is
+    // refused otherwise (sequence_only). Decided on the host with powers of the step matrix: F^L = I and F^(L/q) != I
+    // for the primes q of L (a register whose taps leave out N is singular: never).
+    p->maximal = ((p->G & 1u) && period_is_maximal(p->N, jt)) ? 1 : 0;
+    if (p->N > kMaxTransformOrder || !p->maximal) {
+        // orders 31 and 32 (zmls_internal.h::kMaxTransformOrder) and registers that are not maximum-length: the bit
+        // sequence only. A register that is not maximal does not wrap at L: the buffer's bits past L continue it.
+        int rc = launch_lfsr_tables(p->N, p->G, p->s0, p->d_jt, p->d_bits, p->n_words, nullptr, nullptr, p->maximal, 0);
         if (rc) return rc;
         p->npass = 0;
         ZHIP(hipDeviceSynchronize());
@@ -134,7 +139,7 @@ int build_plan(zmls_plan *p)
     ZHIP(hipMalloc((void **)&p->d_scatter_nat, n * 4));
     ZHIP(hipMemsetAsync(p->d_gather, 0xFF, n * 4, 0));
     ZHIP(hipMemsetAsync(p->d_scatter_nat, 0xFF, n * 4, 0));
-    int rc = launch_lfsr_tables(p->N, p->G, p->s0, p->d_jt, p->d_bits, p->n_words, p->d_gather, p->d_scatter_nat, 0);
+    int rc = launch_lfsr_tables(p->N, p->G, p->s0, p->d_jt, p->d_bits, p->n_words, p->d_gather, p->d_scatter_nat, 1, 0);
     if (rc) return rc;
     // every window value 1..L must have been visited exactly once, else the taps do not give a
     // maximum-length sequence and the Hadamard identity does not hold
@@ -147,9 +152,10 @@ int build_plan(zmls_plan *p)
     ZHIP(hipMemcpy(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost));
     (void)hipFree(d_cnt);
     if (h_cnt[0] || h_cnt[1]) {
-        set_error("taps do not generate a maximum-length sequence of order %d (%llu of %llu register states never occur)",
+        // cannot happen for a register the host found maximal: the kernel's walk and the host's matrix powers disagree
+        set_error("internal error: order %d taps are maximum-length by F^L = I but the walk missed %llu of %llu register states",
                   p->N, h_cnt[0], (unsigned long long)p->L);
-        return ZMLS_E_UNSUPPORTED;
+        return ZMLS_E_HIP;
     }
     p->npass = pass_split(p->N, p->bits);
     // the tall tile earns its single workgroup per CU only where its 11-bit passes save a whole pass over HBM: N = 21, 22
@@ -298,6 +304,13 @@ int zmls_plan_force_tile(zmls_plan *p, int cfg)
 int zmls_plan_set_resident(zmls_plan *p, int mode, size_t bytes, int flags)
 {
     if (!p || mode < -1 || mode > 1) { set_error("cache-resident schedule: mode must be -1 (auto), 0 (off) or 1 (on)"); return ZMLS_E_ARG; }
+    if ((flags & 4) && !p->aux_stream) {
+        ZDEVICE(p->device);
+        int rc = ZMLS_OK;
+        ZHIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+        ZHIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        ZHIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    }
     p->resident_mode = mode;
     p->resident_bytes = bytes;
     p->resident_flags = flags;
@@ -335,6 +348,39 @@ int zmls_sequence_bits(zmls_plan *p, uint8_t *out, int64_t nbits)
     return ZMLS_OK;
 }
 
+int zmls_sequence_bits_from(zmls_plan *p, uint64_t start, uint8_t *out, int64_t nbits)
+{
+    if (!p || !out || nbits < 0 || nbits > ((int64_t)1 << 31)) { set_error("bad sequence_bits_from arguments (at most 2^31 bits per call)"); return ZMLS_E_ARG; }
+    if (!nbits) return ZMLS_OK;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
+    // where the register stands after `start` steps: jump-ahead bookkeeping on the host (matrix powers, as the plan's
+    // own tables are built), then the kernel generates the bits from there. A maximum-length register wraps at L.
+    JumpTables jt;
+    build_jump_tables(p->N, p->G, &jt);
+    const uint32_t s_at = p->maximal ? host_fib_state(p->N, p->G, jt, start % (uint64_t)p->L) : host_fib_state_at(p->N, p->G, jt, start);
+    const uint64_t n_words = (uint64_t)((nbits + 1023) / 1024) * 32;
+    uint32_t *d = nullptr;
+    ZHIP(hipMalloc((void **)&d, n_words * 4));
+    rc = launch_lfsr_tables(p->N, p->G, s_at, p->d_jt, d, n_words, nullptr, nullptr, p->maximal, 0);
+    const size_t nbytes = (size_t)((nbits + 7) / 8);
+    if (!rc) {
+        hipError_t e = hipMemcpy(out, d, nbytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(sequence bits)");
+    }
+    (void)hipFree(d);
+    if (!rc && (nbits & 7)) out[nbytes - 1] &= (uint8_t)((1u << (nbits & 7)) - 1u);
+    return rc;
+}
+
+int zmls_plan_kind(const zmls_plan *p, int *maximal, int *transform)
+{
+    if (!p) { set_error("null argument"); return ZMLS_E_ARG; }
+    if (maximal) *maximal = p->maximal;
+    if (transform) *transform = p->npass > 0;
+    return ZMLS_OK;
+}
+
 int zmls_sequence_device(zmls_plan *p, void *d_out, int dtype, int64_t repeats, int64_t stride, void *stream)
 {
     if (!p || !d_out || repeats < 1 || stride < 1) { set_error("bad sequence_device arguments"); return ZMLS_E_ARG; }
@@ -364,13 +410,18 @@ int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
 } // extern "C"
 
 namespace zmls {
-// plans of orders 31 and 32 hold the bit sequence only
+// plans of orders 31 and 32, and of taps that are not maximum-length, hold the bit sequence only
 int sequence_only(const zmls_plan *p)
 {
     if (p->npass > 0) return ZMLS_OK;
-    set_error("order %d: the sequence is generated, impulse responses are supported up to order %d (one 64-byte-row slab of the "
-              "intermediate of a 2^%d-point transform alone is %.0f GB, beside %d GiB of tables and the capture)", p->N, kMaxTransformOrder, p->N,
-              (double)work_rows_total(p->N) * 64.0 / 1e9, (int)((2ull << p->N) * 4 >> 30));
+    if (!p->maximal)
+        set_error("taps do not generate a maximum-length sequence of order %d: the sequence is generated as the reference generates it, "
+                  "but the impulse response needs the two-valued autocorrelation of a maximum-length sequence (the reference would "
+                  "correlate against a short-period sequence without saying so)", p->N);
+    else
+        set_error("order %d: the sequence is generated, impulse responses are supported up to order %d (one 64-byte-row slab of the "
+                  "intermediate of a 2^%d-point transform alone is %.0f GB, beside %d GiB of tables and the capture)", p->N, kMaxTransformOrder, p->N,
+                  (double)work_rows_total(p->N) * 64.0 / 1e9, (int)((2ull << p->N) * 4 >> 30));
     return ZMLS_E_UNSUPPORTED;
 }
 // the launch sequence of the passes on buffers as they are (no layout adapters)
@@ -503,30 +554,59 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
                                (p->resident_mode > 0 || (p->resident_mode < 0 && periods <= kResidentMaxPeriods));
     const bool resident2 = want_resident && npass == 2 && sbytes <= budget;
     const bool resident3 = want_resident && npass == 3 && pass_bits[1] >= log2_tiles(pass_bits[0], tc) && pass_bits[0] >= log2_tiles(pass_bits[1], tc);
-    if (resident2 && (int64_t)(budget / sbytes) < cap) cap = (int64_t)(budget / sbytes);
+    // Two lanes (tuning flag 4): consecutive chunks alternate between the caller's stream and the plan's second one, each
+    // with half the chunk size, so that one chunk's launch tails run beside the other's bodies; forked and joined with
+    // events, nothing of it is visible to the caller's stream order.
+    const bool two = (resident2 || resident3) && (p->resident_flags & 4) && p->aux_stream && !ev;
+    const size_t lane_budget = two ? budget / 2 : budget;
+    if (resident2) {
+        int64_t want = std::max<int64_t>(1, (int64_t)(lane_budget / sbytes));
+        if (two && cap < 2 * want) want = cap / 2;                  // both lanes' chunks live in the workspace at once
+        if (want >= 1 && want < cap) cap = want;
+    }
+    const bool lanes2 = two && (!resident2 || (int64_t)(work_bytes / sbytes) >= 2 * cap);
+    hipStream_t lane[2] = {st, lanes2 ? p->aux_stream : st};
+    if (lanes2) {
+        ZHIP(hipEventRecord(p->ev_fork, st));
+        ZHIP(hipStreamWaitEvent(p->aux_stream, p->ev_fork, 0));
+    }
     const uint64_t U = 1ull << tc.lu;
     auto swizzle_of = [&](int i, uint32_t n_macro, uint32_t ns) -> uint32_t {
         if (cfg == CFG_BIG || p->swizzle == 0) return 0;
         if (i == 0 || p->work_layout) return (n_macro % 8 == 0) ? ns : 0;
         return (((uint64_t)n_macro * ns) % 16 == 0) ? 2 : 0;
     };
+    int chunk_no = 0;
     for (int64_t s0 = 0; s0 < n_slabs; s0 += cap) {
         const uint32_t ns = (uint32_t)((n_slabs - s0 < cap) ? n_slabs - s0 : cap);
         a.ch_first = s0 * CS;
         a.n_slab_groups = ns;
-        a.work = work;
         a.macro_first = 0;
         a.slab_fastest = p->work_layout;
         a.work_slab_stride = p->work_layout ? U : work_rows_total(p->N) * U;
         a.work_row_stride = p->work_layout ? (uint64_t)ns * U : U;
+        // two-pass orders on two lanes: chunk k runs on lane k & 1 in that lane's half of the workspace
+        hipStream_t gs = st;
+        void *gwork = work;
+        if (resident2 && lanes2) {
+            gs = lane[chunk_no & 1];
+            gwork = (char *)work + (size_t)(chunk_no & 1) * (size_t)cap * sbytes;
+            ++chunk_no;
+        }
+        a.work = gwork;
         int b = 0, first_pass = 0;
         if (resident3) {
             const int K0 = pass_bits[0], K1 = pass_bits[1], K2 = pass_bits[2];
             const int LT0 = log2_tiles(K0, tc), LT1 = log2_tiles(K1, tc);
             const size_t per_top = ((size_t)1 << (K0 + K1)) * (size_t)(U * kVecBytes);       // bytes of one slab's rows under one value of the top bits
-            const uint32_t sub = (uint32_t)std::min<uint64_t>(ns, std::max<uint64_t>(1, budget / per_top));
-            const uint32_t tops = (uint32_t)std::min<uint64_t>(1ull << K2, std::max<uint64_t>(1, budget / (per_top * sub)));
+            const uint32_t sub = (uint32_t)std::min<uint64_t>(ns, std::max<uint64_t>(1, lane_budget / per_top));
+            const uint32_t tops = (uint32_t)std::min<uint64_t>(1ull << K2, std::max<uint64_t>(1, lane_budget / (per_top * sub)));
             if (ev) ZHIP(hipEventRecord(ev[0], st));
+            if (s0 > 0 && lanes2) {
+                // the previous group's third pass reads the workspace this group's chunks are about to overwrite
+                ZHIP(hipEventRecord(p->ev_fork, st));
+                ZHIP(hipStreamWaitEvent(p->aux_stream, p->ev_fork, 0));
+            }
             for (uint32_t ss = 0; ss < ns; ss += sub) {
                 const uint32_t nsub = std::min(sub, ns - ss);
                 a.ch_first = (s0 + ss) * CS;
@@ -534,17 +614,22 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
                 a.work = (char *)work + (size_t)ss * a.work_slab_stride * kVecBytes;
                 for (uint32_t t0 = 0; t0 < (1u << K2); t0 += tops) {
                     const uint32_t nt = std::min(tops, (1u << K2) - t0);
+                    hipStream_t cs = lane[chunk_no++ & 1];
                     a.b = 0; a.macro_first = t0 << (K1 - LT0); a.n_macro = nt << (K1 - LT0);
                     a.swz_group = swizzle_of(0, a.n_macro, nsub);
                     a.work_keep_ld = 0; a.work_keep_st = 1;
-                    rc = launch(cfg, K0, vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM, OUT_WORK, a, st);
+                    rc = launch(cfg, K0, vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM, OUT_WORK, a, cs);
                     if (rc) return rc;
                     a.b = K0; a.macro_first = t0 << (K0 - LT1); a.n_macro = nt << (K0 - LT1);
                     a.swz_group = swizzle_of(1, a.n_macro, nsub);
                     a.work_keep_ld = 1; a.work_keep_st = p->resident_flags & 1;      // on its way to HBM: streams unless told otherwise (tuning)
-                    rc = launch(cfg, K1, IN_WORK, OUT_WORK, a, st);
+                    rc = launch(cfg, K1, IN_WORK, OUT_WORK, a, cs);
                     if (rc) return rc;
                 }
+            }
+            if (lanes2) {
+                ZHIP(hipEventRecord(p->ev_join, p->aux_stream));
+                ZHIP(hipStreamWaitEvent(st, p->ev_join, 0));
             }
             if (ev) ZHIP(hipEventRecord(ev[1], st));
             a.ch_first = s0 * CS; a.n_slab_groups = ns; a.work = work; a.macro_first = 0;
@@ -562,7 +647,7 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
             a.work_keep_st = resident2 ? 1 : 0;
             a.work_keep_ld = (resident2 && !(p->resident_flags & 2)) ? 1 : 0;
             if (ev) ZHIP(hipEventRecord(ev[2 * i], st));
-            rc = launch(cfg, K, inm, outm, a, st);
+            rc = launch(cfg, K, inm, outm, a, gs);
             if (rc) return rc;
             if (ev) ZHIP(hipEventRecord(ev[2 * i + 1], st));
             b += K;
@@ -575,6 +660,10 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
                 ZHIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
                 pass_ms[i] += ms;
             }
+    }
+    if (resident2 && lanes2) {
+        ZHIP(hipEventRecord(p->ev_join, p->aux_stream));
+        ZHIP(hipStreamWaitEvent(st, p->ev_join, 0));
     }
     return ZMLS_OK;
 }

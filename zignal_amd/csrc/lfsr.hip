@@ -27,7 +27,7 @@ constexpr int kLfsrBlock = 64;      // one wave per workgroup: N=20 is 256 workg
 
 __global__ void __launch_bounds__(kLfsrBlock) lfsr_tables_kernel(int N, uint32_t G, uint32_t s0, const JumpTables *__restrict__ jt,
                                                           uint32_t *__restrict__ bits, uint64_t n_words,
-                                                          uint32_t *__restrict__ gather, uint32_t *__restrict__ scatter_nat)
+                                                          uint32_t *__restrict__ gather, uint32_t *__restrict__ scatter_nat, int wrap)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t n0 = t * kBitsPerThread;
@@ -36,12 +36,15 @@ __global__ void __launch_bounds__(kLfsrBlock) lfsr_tables_kernel(int N, uint32_t
 
     uint32_t s = s0;      // window at n = 0
     uint32_t c = 1u;      // C[0]
-    const uint64_t jump = n0 % L;         // the registers have period L; the bit buffer runs a little past it (and past 2^32 at N = 32)
+    // maximum-length registers have period L; the bit buffer runs a little past it (and past 2^32 at N = 32). Any other
+    // register keeps running as the reference's does (mls.py:104-115): no wrap, and F^(2^32) is F^(2^31) twice.
+    const uint64_t jump = wrap ? n0 % L : n0;
     for (int k = 0; k < 32; ++k)
         if ((jump >> k) & 1ull) {
             s = gf2_apply(jt->fib[k], s, N);
             c = gf2_apply(jt->gal[k], c, N);
         }
+    if (jump >> 32) s = gf2_apply(jt->fib[31], gf2_apply(jt->fib[31], s, N), N);       // (no tables there: c is not used)
     for (int w = 0; w < kBitsPerThread / 32; ++w) {
         uint32_t word = 0;
         for (int j = 0; j < 32; ++j) {
@@ -174,11 +177,11 @@ inline uint32_t grid_for(int64_t n, int cap = 8192)
 } // namespace
 
 int launch_lfsr_tables(int N, uint32_t G, uint32_t s0, const JumpTables *d_jt, uint32_t *d_bits, uint64_t n_words,
-                       uint32_t *d_gather, uint32_t *d_scatter_nat, hipStream_t st)
+                       uint32_t *d_gather, uint32_t *d_scatter_nat, int wrap, hipStream_t st)
 {
     const uint64_t threads = (n_words * 32 + kBitsPerThread - 1) / kBitsPerThread;
     const uint32_t blocks = (uint32_t)((threads + kLfsrBlock - 1) / kLfsrBlock);
-    hipLaunchKernelGGL(lfsr_tables_kernel, dim3(blocks), dim3(kLfsrBlock), 0, st, N, G, s0, d_jt, d_bits, n_words, d_gather, d_scatter_nat);
+    hipLaunchKernelGGL(lfsr_tables_kernel, dim3(blocks), dim3(kLfsrBlock), 0, st, N, G, s0, d_jt, d_bits, n_words, d_gather, d_scatter_nat, wrap);
     ZHIP(hipGetLastError());
     return ZMLS_OK;
 }

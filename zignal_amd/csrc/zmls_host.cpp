@@ -46,7 +46,9 @@ void build_jump_tables(int N, uint32_t G, JumpTables *jt)
 static uint32_t taps_to_mask(int N, const int32_t *taps, int ntaps)
 {
     uint32_t G = 0;
-    for (int i = 0; i < ntaps; ++i) G ^= 1u << (N - taps[i]);   // a tap listed twice cancels, as XOR does in mls.py:106-107
+    // a tap listed twice cancels, as XOR does in mls.py:106-107; a tap N < t <= 2N reads shiftregister[N - t], a negative
+    // index, which Python counts from the newest cell: the same cell as tap t - N
+    for (int i = 0; i < ntaps; ++i) G ^= 1u << (N - (taps[i] > N ? taps[i] - N : taps[i]));
     return G;
 }
 
@@ -63,6 +65,18 @@ uint32_t host_fib_state(int N, uint32_t G, const JumpTables &jt, uint64_t steps)
     uint32_t s = initial_window(N, G);
     for (int k = 0; k < 32; ++k)
         if ((steps >> k) & 1ull) s = gf2_apply(jt.fib[k], s, N);
+    return s;
+}
+
+// the window after `steps` steps for any 64-bit step count (registers that are not maximum-length do not wrap at L)
+uint32_t host_fib_state_at(int N, uint32_t G, const JumpTables &jt, uint64_t steps)
+{
+    uint32_t s = initial_window(N, G);
+    Gf2Map P = jt.fib[31], Q;
+    for (int k = 0; k < 64; ++k) {
+        if (k >= 32) { square(P, &Q, N); P = Q; }          // F^(2^k) beyond the table
+        if ((steps >> k) & 1ull) s = gf2_apply(k < 32 ? jt.fib[k] : P, s, N);
+    }
     return s;
 }
 
@@ -91,6 +105,7 @@ static Gf2Map map_power(const JumpTables &jt, uint64_t e, int N)
 }
 bool period_is_maximal(int N, const JumpTables &jt)
 {
+    // (a register whose taps leave out N has a singular step matrix: no power of it is the identity)
     const uint64_t L = (1ull << N) - 1;
     if (!map_is_identity(map_power(jt, L, N), N)) return false;
     uint64_t rest = L;
@@ -107,10 +122,11 @@ int validate_taps(int N, const int32_t *taps, int ntaps, uint32_t *G, uint32_t *
 {
     if (N < 2 || N > kMaxSequenceOrder) { set_error("MLS order N=%d outside the supported range 2..%d", N, kMaxSequenceOrder); return ZMLS_E_ARG; }
     if (!taps || ntaps < 1 || ntaps > 32) { set_error("need 1..32 feedback taps"); return ZMLS_E_ARG; }
+    // the reference checks nothing (mls.py:64-68): every tap its register can index generates a sequence, maximum-length
+    // or not (taps 1..N, and N+1..2N through Python's negative indices); anything else is its IndexError at the first bit
     for (int i = 0; i < ntaps; ++i)
-        if (taps[i] < 1 || taps[i] > N) { set_error("tap %d outside 1..N (N=%d)", (int)taps[i], N); return ZMLS_E_ARG; }
+        if (taps[i] < 1 || taps[i] > 2 * N) { set_error("deque index out of range: tap %d of a register of N=%d cells", (int)taps[i], N); return ZMLS_E_ARG; }
     *G = taps_to_mask(N, taps, ntaps);
-    if (!(*G & 1u)) { set_error("feedback taps must include N=%d (register length)", N); return ZMLS_E_ARG; }
     *s0 = initial_window(N, *G);
     return ZMLS_OK;
 }

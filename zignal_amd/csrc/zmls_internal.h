@@ -63,6 +63,7 @@ struct JumpTables {
 };
 void build_jump_tables(int N, uint32_t G, JumpTables *jt);            // host
 uint32_t host_fib_state(int N, uint32_t G, const JumpTables &jt, uint64_t steps);
+uint32_t host_fib_state_at(int N, uint32_t G, const JumpTables &jt, uint64_t steps);     // any 64-bit position, no wrap at L
 bool period_is_maximal(int N, const JumpTables &jt);                  // host; used where no tables are built
 
 // ---- pass launch description
@@ -152,7 +153,7 @@ int launch_pass_f32(int cfg, int K, int inm, int outm, const PassArgs &a, hipStr
 
 // ---- plan-time kernels (lfsr.hip)
 int launch_lfsr_tables(int N, uint32_t G, uint32_t s0, const JumpTables *d_jt, uint32_t *d_bits,
-                       uint64_t n_words, uint32_t *d_gather, uint32_t *d_scatter_nat, hipStream_t st);
+                       uint64_t n_words, uint32_t *d_gather, uint32_t *d_scatter_nat, int wrap, hipStream_t st);
 int launch_scatter_perm(int N, int K, TileCfg cfg, int b, const uint32_t *d_scatter_nat, uint32_t *d_scatter_perm,
                         hipStream_t st);
 int launch_sequence_expand(const uint32_t *d_bits, int64_t L, void *d_out, int dtype, int64_t repeats,
@@ -187,6 +188,7 @@ struct zmls_plan {
     int tall_npass;               // pass split of the tall tile (11 bits per pass), 0 when it saves no pass
     int tall_bits[4];
     uint32_t s0;                  // Fibonacci state at n = 0 (first N sequence bits)
+    int maximal;                  // the register's period is 2^N - 1 (else: the sequence is generated, the transform refused)
     uint32_t *d_bits;             // packed sequence bits, n_words uint32
     uint64_t n_words;
     uint32_t *d_gather;           // Q[d], 2^N
@@ -205,5 +207,7 @@ struct zmls_plan {
     int work_layout;              // 0: workspace slab-major, 1: row-major with slab-fastest block order in every pass
     int resident_mode;            // cache-resident schedule: -1 auto (few periods), 0 off, 1 on
     size_t resident_bytes;        // its chunk size (0: kResidentBytes)
-    int resident_flags;           // tuning: 1 = pass 2 of three keeps its stores in the cache too, 2 = non-temporal loads of the resident intermediate
+    hipStream_t aux_stream;       // second lane of the cache-resident schedule and its fork / join events (created on demand)
+    hipEvent_t ev_fork, ev_join;
+    int resident_flags;           // tuning: 4 = chunks alternate between two streams, 1 = pass 2 of three keeps its stores in the cache too, 2 = non-temporal loads of the resident intermediate
 };

@@ -123,6 +123,18 @@ class Plan:
         L.check(L.lib().zmls_sequence_bits(self._h, out.ctypes.data, nbits))
         return out
 
+    def bits_from(self, start, nbits):
+        """bits start..start+nbits-1 of the endless generator (the register keeps running; zmls_sequence_bits_from), one per element"""
+        out = np.zeros((int(nbits) + 7) // 8, dtype=np.uint8)
+        L.check(L.lib().zmls_sequence_bits_from(self._h, int(start), out.ctypes.data, int(nbits)))
+        return np.unpackbits(out, bitorder="little")[:int(nbits)]
+
+    def kind(self):
+        """(maximal, transform): is the register maximum-length; do the impulse-response entry points work on this plan"""
+        m, t = ctypes.c_int(), ctypes.c_int()
+        L.check(L.lib().zmls_plan_kind(self._h, ctypes.byref(m), ctypes.byref(t)))
+        return bool(m.value), bool(t.value)
+
     def sequence(self, repeats=1):
         out = np.empty((repeats * self.L, 1), dtype=np.float64)
         L.check(L.lib().zmls_sequence_f64(self._h, out.ctypes.data, int(repeats)))

@@ -60,7 +60,12 @@ class _MLS_base(object):
     # sequence on every call, mls.py:207)
     def _plan(self):
         if self._plan_obj is None:
-            self._plan_obj = Plan(self.N, self.taps, dtype=self._dtype, device=self._device)
+            try:
+                self._plan_obj = Plan(self.N, self.taps, dtype=self._dtype, device=self._device)
+            except _L.ZmlsError as e:
+                if e.code == _L.E_ARG and e.msg.startswith("deque index out of range"):
+                    raise IndexError("deque index out of range") from None      # shiftregister[self.N-tap], mls.py:107
+                raise
         return self._plan_obj
 
     def _bits(self):
@@ -82,22 +87,38 @@ class _MLS_base(object):
         s += '-----------------:---------------------\n'
         return s
 
-    # ---- generators (mls.py:91-152). The bits come from the device plan; the generators only
-    # hand them out, endlessly, wrapping at L as the shift register does.
-    def generator_bit(self):
-        bits = self._bits()
-        i = 0
-        while True:
-            yield int(bits[i])
-            i = i + 1 if i + 1 < self.L else 0
+    # ---- generators (mls.py:91-152). The bits come from the device plan; the generators only hand them out, endlessly.
+    # A maximum-length register repeats after L bits, so one period is fetched once and wraps. Taps the reference also
+    # accepts but that are not maximum-length (it checks nothing, mls.py:64-68) keep their register running without
+    # any such period: their bits are fetched block by block from where the generator stands (zmls_sequence_bits_from).
+    _BLOCK = 1 << 16
 
-    def generator_chunk(self, chunk=1024):
-        bits = self._bits()
+    def generator_bit(self):
+        if self._plan().kind()[0]:
+            bits = self._bits()
+            i = 0
+            while True:
+                yield int(bits[i])
+                i = i + 1 if i + 1 < self.L else 0
         pos = 0
         while True:
-            idx = (pos + np.arange(chunk)) % self.L
-            pos = (pos + chunk) % self.L
-            yield bits[idx].reshape(chunk, 1)
+            for b in self._plan().bits_from(pos, self._BLOCK):
+                yield int(b)
+            pos += self._BLOCK
+
+    def generator_chunk(self, chunk=1024):
+        maximal = self._plan().kind()[0]
+        bits = self._bits() if maximal else None
+        pos = 0
+        while True:
+            if maximal:
+                idx = (pos + np.arange(chunk)) % self.L
+                pos = (pos + chunk) % self.L
+                yield bits[idx].reshape(chunk, 1)
+            else:
+                block = self._plan().bits_from(pos, chunk).astype(np.int64)
+                pos += chunk
+                yield block.reshape(chunk, 1)
 
     def generator_samples(self, chunk=1024):
         for block in self.generator_chunk(chunk):
