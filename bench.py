@@ -9,8 +9,10 @@ Workload (BASELINE.json config 3, one GPU's share): order N=20, 512 channels x 1
 (Nsamples, Nchannels) layout. A "step" is one pass of the whole hot path over that batch:
 gather + average + FWHT + scatter + /L, all channels. Inputs are resident in HBM before the timed
 region. With N > 1 every rank owns its own 512 channels (captures are independent: no data-path
-collective, weak scaling); torch.distributed (gloo, CPU tensors) is used only for the barrier
-and the max-over-ranks of the step time. The library itself has no PyTorch dependency.
+collective, weak scaling). The ranks are launched by the driver's torch.distributed.run or by
+`bench.py --gpus N` itself (N children, one per GPU); either way a rank only reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_PORT from its environment. Barrier, max over ranks and the RCCL id bytes go over
+zignal_amd.rendezvous (localhost TCP, standard library): nothing here imports PyTorch.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     : algorithmic bytes of one step / device time of its kernels (HIP events), vs 8 TB/s,
@@ -38,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from zignal_amd import _lib, multi  # noqa: E402
+from zignal_amd.rendezvous import Rendezvous  # noqa: E402
 from zignal_amd.device import DeviceBuffer, Plan, Timer, download_channel, sync  # noqa: E402
 from zignal_amd.measure.mlstaps import TAPS  # noqa: E402
 
@@ -74,12 +77,13 @@ def parse():
     ap.add_argument("--period-leg", default="auto", choices=["auto", "none"],
                     help="N>1: also run the period-sharded RCCL leg after the channel-mode timing (auto) or not (none)")
     ap.add_argument("--period-leg-steps", type=int, default=3)
+    ap.add_argument("--rendezvous-timeout", type=float, default=900.0, help="seconds a rank waits for the others at a barrier before it gives up")
     ap.add_argument("--period-leg-timeout", type=float, default=240.0, help="seconds before the RCCL leg is given up (its result is then an error entry)")
     return ap.parse_args()
 
 
 class quiet_stdout:
-    """gloo and RCCL report on stdout (C++ side); stdout carries the one JSON line."""
+    """RCCL reports on stdout (C++ side); stdout carries the one JSON line."""
 
     def __enter__(self):
         sys.stdout.flush()
@@ -252,9 +256,15 @@ def per_kernel(pass_ms, Ravg, L, es, C):
     passes read and write one batch each; a single-pass plan reads the capture and writes the responses) over its own
     HIP-event time: how close each kernel is to what this part streams"""
     out = []
+    merged = len(pass_ms) == 3 and pass_ms[1] == 0        # three-pass orders on the cache-resident schedule: passes 1 and 2 run chunk by chunk
     for i, ms in enumerate(pass_ms):
+        if merged and i == 1:
+            continue
         by = ((Ravg + 1) if i == 0 else 2) * L * es * C
-        out.append({"kernel": "pass %d" % (i + 1), "ms": float(ms), "bytes_by_design": int(by),
+        name = "pass %d" % (i + 1)
+        if merged and i == 0:
+            by, name = (Ravg + 3) * L * es * C, "passes 1+2 (chunks of top-bit ranges, intermediate in the Infinity Cache)"
+        out.append({"kernel": name, "ms": float(ms), "bytes_by_design": int(by),
                     "GBps": by / (ms * 1e-3) / 1e9 if ms > 0 else None})
     return out
 
@@ -397,11 +407,10 @@ def order_sweep(dev):
 
 
 # --------------------------------------------------------------------------------------------- the RCCL leg
-def period_leg(args, world, rank, dev, dist, plan, dtype_code, es, C, R, result):
+def period_leg(args, world, rank, dev, rdzv, plan, dtype_code, es, C, R, result):
     """The same batch with the periods, not the channels, spread over the ranks (second mode): rank r
     holds periods r, r+world, ... of ALL world*C channels, adds them up, the partial sums are reduce-scattered with RCCL
     (zmls_impulse_period_sharded_device), and rank r transforms channel block r. Fills `result` in place."""
-    import torch
     L = plan.L
     Ct = world * C
     mine, skip, total = multi.period_shard(R, world, rank)
@@ -411,13 +420,12 @@ def period_leg(args, world, rank, dev, dist, plan, dtype_code, es, C, R, result)
 
     def agreed(what, fn):
         """run fn on every rank; all ranks learn whether it worked everywhere (a rank that went on alone would hang the rest)"""
-        ok, err = torch.ones(1, dtype=torch.int32), ""
+        ok, err = 1.0, ""
         try:
             fn()
         except Exception as e:  # noqa: BLE001  (RCCL refuses e.g. two ranks on one device)
-            ok[0], err = 0, "%s: %s" % (type(e).__name__, e)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
+            ok, err = 0.0, "%s: %s" % (type(e).__name__, e)
+        if rdzv.min(ok) == 0.0:
             result["error"] = "%s failed over %d ranks: %s" % (what, world, err or "on another rank")
             for k in ("d_x", "d_h"):
                 if k in state:
@@ -427,8 +435,11 @@ def period_leg(args, world, rank, dev, dist, plan, dtype_code, es, C, R, result)
             return False
         return True
 
+    def which_rccl():
+        state["lib"] = multi.rccl_library()
+
     def make_comm():
-        blob = multi.torch_exchange(dist, rank, multi.make_unique_id)
+        blob = rdzv.broadcast(multi.make_unique_id)
         with quiet_stdout():
             state["comm"] = multi.Comm(blob, rank, world, dev)
 
@@ -440,6 +451,10 @@ def period_leg(args, world, rank, dev, dist, plan, dtype_code, es, C, R, result)
             plan.synth_device(state["d_x"].ptr, dtype_code, len(mine), Ct, Ct, 1, seed=SEED, sigma=1e-3)
         sync(dev)
 
+    if not agreed("loading librccl", which_rccl):
+        return
+    # which RCCL answered, on every rank (a first multi-GPU record should explain itself)
+    result["librccl_path"], result["librccl_version"] = state["lib"]
     if not agreed("ncclCommInitRank", make_comm) or not agreed("staging for the exchange", make_buffers):
         return
     comm, d_x, d_h, ps = state["comm"], state["d_x"], state["d_h"], state["ps"]
@@ -449,25 +464,25 @@ def period_leg(args, world, rank, dev, dist, plan, dtype_code, es, C, R, result)
         ps.impulse_device(d_x.ptr, dtype_code, n_rows, skip, total, Ct, Ct, 1, d_h.ptr, C, 1)
     step()
     sync(dev)
-    dist.barrier()
+    rdzv.barrier()
     steps = max(1, args.period_leg_steps)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     sync(dev)
-    dist.barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ms = float(t.item()) / steps * 1e3
-    err_sys = torch.tensor([system_check(plan, d_h, dtype_code, C, C, 1, SEED, rank * C)], dtype=torch.float64)
-    dist.all_reduce(err_sys, op=dist.ReduceOp.MAX)
+    mine_ms = (time.perf_counter() - t0) / steps * 1e3         # this rank alone, before it waits for the others
+    rdzv.barrier()
+    per_rank = rdzv.gather_floats(mine_ms)
+    ms = rdzv.max((time.perf_counter() - t0) / steps * 1e3)
+    err_sys = rdzv.max(system_check(plan, d_h, dtype_code, C, C, 1, SEED, rank * C))
     sent = (world - 1) * C * L * es                     # bytes of partial sums that leave each GPU per step
     result.update({
         "ms_per_step": ms, "steps": steps, "chunk_channels": comm.info()["chunk_channels"],
+        "ms_per_step_per_rank": {"min": min(per_rank), "max": max(per_rank), "all": per_rank},
         "value": Ct * total * L / (ms * 1e-3) / 1e9, "unit": "Gsamples/s",
         "bytes_exchanged_per_gpu_per_step": sent, "GBps_exchanged_per_gpu": sent / (ms * 1e-3) / 1e9,
         "periods_held_by_rank0": len(multi.period_shard(R, world, 0)[0]),
-        "system_check_max_abs_err": float(err_sys.item()),
+        "system_check_max_abs_err": err_sys,
         "workload": "the same %d channels x %d averaged periods, periods striped over %d GPUs; every rank adds up its periods, "
                     "ncclReduceScatter(sum) of the partial sums in chunks of %d channels, rank r transforms channel block r"
                     % (Ct, total, world, comm.info()["chunk_channels"]),
@@ -477,25 +492,32 @@ def period_leg(args, world, rank, dev, dist, plan, dtype_code, es, C, R, result)
     comm.close()
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` started by hand: N children of this process, one per GPU, before anything here has touched a
+    GPU (a process that has must never be replaced, and is not: the children are ordinary subprocesses). Rank 0's stdout
+    is ours; the exit status is the worst of theirs."""
+    port = os.environ.get("MASTER_PORT", "29517")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    for pr in procs:
+        rc = pr.wait()
+        worst = worst or rc
+    return worst
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
-        # not launched under torch.distributed.run: start it as a child and pass its exit code on
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
-               os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        with quiet_stdout():
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            dist.barrier()
+        sys.exit(launch_ranks(args.gpus))
+    # barrier, max over ranks, id bytes: localhost TCP among the ranks of this launch (no PyTorch, no gloo)
+    rdzv = Rendezvous(rank, world, timeout_s=args.rendezvous_timeout)
+    rdzv.barrier()
 
     N, C, Ravg = args.order, args.channels, args.periods
     R = Ravg + 1
@@ -549,10 +571,7 @@ def main():
         mine, skip, total = multi.period_shard(R, world, rank)
         n_rows = len(mine) * L
         d_x = DeviceBuffer(max(n_rows, 1) * Ct * es, dev)
-        if world > 1:
-            blob = multi.torch_exchange(dist, rank, multi.make_unique_id)
-        else:
-            blob = multi.make_unique_id()
+        blob = rdzv.broadcast(multi.make_unique_id)
         with quiet_stdout():
             comm = multi.Comm(blob, rank, world, dev)
         ps = multi.PeriodSharded(plan, comm, min(args.chunk_channels, C))
@@ -565,8 +584,7 @@ def main():
 
     def barrier():
         sync(dev)
-        if dist is not None:
-            dist.barrier()
+        rdzv.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -580,12 +598,9 @@ def main():
     sync(dev)
     elapsed = time.perf_counter() - t0
     pipeline_ms = tm.elapsed_ms() / args.steps
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    per_rank_ms = rdzv.gather_floats(elapsed / args.steps * 1e3)     # every rank's own time; the job's is the slowest
+    elapsed = max(per_rank_ms) * args.steps / 1e3
+    per_rank_kernel_ms = rdzv.gather_floats(pipeline_ms)
 
     # ---- kernel-level timing on the launch stream (HIP events around every pass kernel)
     pass_ms = np.zeros(plan.info()["passes"])
@@ -623,6 +638,10 @@ def main():
             "per_kernel": per_kernel(pass_ms, Ravg, L, es, C),
         },
         "plan_build_s": plan_build_s,
+        # the spread over the ranks (placement plateaus differ from GPU to GPU: DESIGN.md §3): wall time per step of every
+        # rank, and the HIP-event time of its launch sequences
+        "per_rank": {"ms_per_step": per_rank_ms, "kernel_ms_per_step": per_rank_kernel_ms,
+                     "min_ms": min(per_rank_ms), "max_ms": max(per_rank_ms)},
         # what the placement search of the capture bought: gather-pass ms of the first candidate (= one plain hipMalloc
         # in this process) against the buffer the steps above ran on
         "capture_placement": placement,
@@ -675,7 +694,7 @@ def main():
         # the RCCL leg must never cost the line above: it runs beside a deadline, and a rank that finds it stuck
         # reports that and leaves
         result = {}
-        th = threading.Thread(target=lambda: _guard(period_leg, result, args, world, rank, dev, dist, plan, dtype_code, es, C, R, result), daemon=True)
+        th = threading.Thread(target=lambda: _guard(period_leg, result, args, world, rank, dev, rdzv, plan, dtype_code, es, C, R, result), daemon=True)
         th.start()
         th.join(args.period_leg_timeout)
         if th.is_alive():
@@ -683,7 +702,10 @@ def main():
             out["period_mode"] = result
             if rank == 0:
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            # the line is out; the status still says that a leg hung (a daemon thread may be stuck inside RCCL: no clean-up)
+            sys.stderr.write("rank %d: %s\n" % (rank, result["error"]))
+            sys.stderr.flush()
+            os._exit(4)
         out["period_mode"] = result
     plan.close()
 
@@ -709,12 +731,11 @@ def main():
             print("CONFIG FAILURE: %s" % json.dumps(bad)[:2000], file=sys.stderr)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        try:
-            dist.barrier()
-            dist.destroy_process_group()
-        except Exception as e:  # noqa: BLE001  (a rank that left early must not turn a printed line into a failure)
-            print("rank %d: %s at the closing barrier" % (rank, type(e).__name__), file=sys.stderr)
+    try:
+        rdzv.barrier()
+    except (TimeoutError, ConnectionError, OSError) as e:      # a rank that left early must not turn a printed line into a failure
+        print("rank %d: %s at the closing barrier" % (rank, type(e).__name__), file=sys.stderr)
+    rdzv.close()
 
 
 def _guard(fn, result, *a):

@@ -192,6 +192,9 @@ typedef struct zmls_comm zmls_comm;
 int zmls_comm_unique_id(uint8_t *id /* ZMLS_COMM_ID_BYTES */);
 int zmls_comm_create(zmls_comm **out, const uint8_t *id, int rank, int n_ranks, int device);
 int zmls_comm_destroy(zmls_comm *c);
+/* which librccl answered (the file the loader resolved; the ROCm installation's own is tried first, by absolute path,
+ * $ZMLS_RCCL_LIBRARY overrides) and its ncclGetVersion code. Either pointer may be null. Loads the library. */
+int zmls_comm_library_info(char *path, size_t path_bytes, int *version);
 /* info[0]=rank info[1]=ranks info[2]=device info[3]=chunk channels info[4]=staging bytes */
 int zmls_comm_info(const zmls_comm *c, int64_t info[8]);
 /* Staging for zmls_impulse_period_sharded_device: the exchange handles `chunk_ch` channels of every

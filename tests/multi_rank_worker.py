@@ -10,7 +10,7 @@ period-sharded: rank r keeps only the periods `period_shard` gives it, adds them
     (gloo has no reduce_scatter on CPU tensors: all_reduce + take block `rank`), rank r divides by the
     total and correlates its block; all-gathered, that must again equal the oracle on the whole capture.
 
-Also: rank 0's 128 id bytes reach rank 1 through `torch_exchange`."""
+Also: rank 0's 128 id bytes reach rank 1 through a gloo broadcast."""
 import os
 import sys
 
@@ -25,6 +25,15 @@ from oracle import c_oracle, mls_oracle  # noqa: E402
 from zignal_amd import multi  # noqa: E402
 
 
+def torch_exchange(dist, rank, make_id):
+    """the 128 id bytes of rank 0 on every rank, over gloo (a host program that already uses torch.distributed)"""
+    t = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(make_id()), dtype=torch.uint8).clone()
+    dist.broadcast(t, src=0)
+    return bytes(t.numpy().tobytes())
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,7 +45,7 @@ def main():
     want = np.stack([mls_oracle.get_impulse(N, taps, np.ascontiguousarray(x[:, c:c + 1]), ref=ref)[:, 0] for c in range(C)], axis=1)
 
     # ---- id bootstrap
-    blob = multi.torch_exchange(dist, rank, lambda: bytes((7 * i + 3) % 256 for i in range(128)))
+    blob = torch_exchange(dist, rank, lambda: bytes((7 * i + 3) % 256 for i in range(128)))
     assert blob == bytes((7 * i + 3) % 256 for i in range(128))
 
     # ---- channel-sharded: no exchange on the data path

@@ -61,12 +61,22 @@ def test_bench_prints_one_json_line_with_the_agreed_fields(extra):
 
 
 @pytest.mark.gpu
-def test_two_ranks_print_one_json_line_too():
-    """The driver's N > 1 launch (torch.distributed.run, one rank per GPU; both ranks share the card on a one-GPU box):
-    rank 0 alone prints, and nothing else (gloo's connection report, RCCL's banner) reaches stdout."""
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--order", "14", "--channels", "32",
-                        "--periods", "3", "--steps", "3", "--warmup", "1"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+@pytest.mark.parametrize("launcher", ["bench.py --gpus 2", "torch.distributed.run"])
+def test_two_ranks_print_one_json_line_too(launcher):
+    """N > 1, both ways it is launched: `bench.py --gpus 2` starting its own two ranks, and the driver's
+    torch.distributed.run (which only sets the environment: the ranks themselves never import torch). Both ranks share
+    the card on a one-GPU box. Rank 0 alone prints, and nothing else (RCCL's banner) reaches stdout."""
+    args = ["--gpus", "2", "--order", "14", "--channels", "32", "--periods", "3", "--steps", "3", "--warmup", "1"]
+    if launcher.startswith("bench.py"):
+        env = dict(os.environ, MASTER_PORT="29543")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        env = dict(os.environ)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29541", os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -74,16 +84,37 @@ def test_two_ranks_print_one_json_line_too():
     assert REQUIRED <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     L = (1 << 14) - 1
     assert abs(d["value"] - 2 * 32 * 3 * L / (d["ms_per_step"] * 1e-3) / 1e9) <= 1e-6 * d["value"]
+    # every rank's own step time is in the line; the job's is the slowest rank's
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and abs(max(pr["ms_per_step"]) - d["ms_per_step"]) <= 1e-9 * d["ms_per_step"] and pr["min_ms"] <= pr["max_ms"]
     # the RCCL leg rides on every N > 1 run. Two ranks on two GPUs: a two-rank communicator moved the partial sums.
     # Two ranks sharing the one GPU of a test box: RCCL refuses the communicator, every rank learns of it, and the
-    # line says so instead of a number.
+    # line says so instead of a number. Either way the line names the librccl that answered: the ROCm installation's,
+    # not one that came along with a Python package.
     pm = d["period_mode"]
+    assert pm["librccl_path"].startswith("/opt/rocm") and "torch" not in pm["librccl_path"] and pm["librccl_version"] > 0, pm
     if "error" in pm:
         assert _lib.device_count() < 2, pm["error"]
         assert "ncclCommInitRank" in pm["error"]
     else:
         assert pm["rccl_ranks"] == 2 and pm["ms_per_step"] > 0 and pm["GBps_exchanged_per_gpu"] > 0
-        assert pm["system_check_max_abs_err"] < 1e-4
+        assert pm["system_check_max_abs_err"] < 1e-4 and len(pm["ms_per_step_per_rank"]["all"]) == 2
+
+
+@pytest.mark.gpu
+def test_a_stuck_period_leg_prints_the_line_and_leaves_with_a_non_zero_status():
+    """A leg that does not finish must not cost the headline its line, and must not look like success either: with a
+    deadline it cannot meet (0 s) the line is printed with period_mode.error and the status is 4."""
+    env = dict(os.environ, MASTER_PORT="29545")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--order", "14", "--channels", "32", "--periods", "3", "--steps", "2",
+                        "--warmup", "1", "--period-leg-timeout", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and "did not finish" in d["period_mode"]["error"]
+    assert r.returncode == 4, r.returncode
 
 
 @pytest.mark.gpu

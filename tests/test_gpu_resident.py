@@ -46,6 +46,10 @@ def test_two_pass_orders_chunked_by_channel_slabs(N, C, R, dtype, tile):
     assert np.array_equal(responses(p, dx, dh, R * L, C, np_dt), want)
     p.set_resident(1, 0, 2)                                           # tuning flag: resident stores, streaming loads
     assert np.array_equal(responses(p, dx, dh, R * L, C, np_dt), want)
+    for nbytes in (0, int(3.3 * base), int(6.6 * base)):              # two lanes: chunks alternate between two streams
+        p.set_resident(1, nbytes, 4)
+        assert np.array_equal(responses(p, dx, dh, R * L, C, np_dt), want), ("two lanes", nbytes)
+        assert np.array_equal(responses(p, dx, dh, R * L, C, np_dt), want), ("two lanes, again", nbytes)
     ref = c_oracle.sequence(N, taps)
     for c in (0, C - 1):
         assert rel_err(want[:, c], oracle_ir(N, taps, x[:, c:c + 1].astype(np.float64), ref)) <= (1e-12 if dtype == "f64" else 1e-5)
@@ -70,7 +74,7 @@ def test_three_pass_orders_chunked_by_ranges_of_the_top_bits(N, C, dtype, tile):
     p.set_resident(0)
     want = responses(p, dx, dh, R * L, C, np_dt)
     # the built-in chunk size; a chunk of one top-bit value of one slab (the smallest there is); a few of them; all slabs at once
-    for nbytes, flags in ((0, 0), (1 << 20, 0), (40 << 20, 0), (0, 1), (700 << 20, 0)):
+    for nbytes, flags in ((0, 0), (1 << 20, 0), (40 << 20, 0), (0, 1), (700 << 20, 0), (0, 4), (40 << 20, 4), (1 << 20, 5)):
         p.set_resident(1, nbytes, flags)
         assert np.array_equal(responses(p, dx, dh, R * L, C, np_dt), want), (nbytes, flags)
     p.set_resident(-1)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "zmls_capture_free": [c_vp, c_vp],
     "zmls_average_host": [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp],
     "zmls_comm_unique_id": [c_vp],
+    "zmls_comm_library_info": [ctypes.c_char_p, c_sz, ctypes.POINTER(c_int)],
     "zmls_comm_create": [_vpp, c_vp, c_int, c_int, c_int],
     "zmls_comm_destroy": [c_vp],
     "zmls_comm_loopback_hub_create": [_vpp, c_int],

@@ -550,10 +550,9 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
     // stream is what counts and the non-temporal pair of round 2 stays (fwht_kernels.inc).
     const size_t sbytes = slab_bytes(p, cfg);
     const size_t budget = p->resident_bytes ? p->resident_bytes : kResidentBytes;
-    const bool want_resident = !gather_pass_only && p->work_layout == 0 &&
-                               (p->resident_mode > 0 || (p->resident_mode < 0 && periods <= kResidentMaxPeriods));
-    const bool resident2 = want_resident && npass == 2 && sbytes <= budget;
-    const bool resident3 = want_resident && npass == 3 && pass_bits[1] >= log2_tiles(pass_bits[0], tc) && pass_bits[0] >= log2_tiles(pass_bits[1], tc);
+    const bool want_resident = p->work_layout == 0 && (p->resident_mode > 0 || (p->resident_mode < 0 && periods <= kResidentMaxPeriods));
+    const bool resident2 = want_resident && npass == 2 && sbytes <= budget;       // (the placement probe's lone gather pass runs in the same chunks)
+    const bool resident3 = want_resident && !gather_pass_only && npass == 3 && pass_bits[1] >= log2_tiles(pass_bits[0], tc) && pass_bits[0] >= log2_tiles(pass_bits[1], tc);
     // Two lanes (tuning flag 4): consecutive chunks alternate between the caller's stream and the plan's second one, each
     // with half the chunk size, so that one chunk's launch tails run beside the other's bodies; forked and joined with
     // events, nothing of it is visible to the caller's stream order.

@@ -32,12 +32,18 @@ struct Rccl {
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    char path[512] = "";          // the file the loader resolved (dladdr), for the benchmark's line
     char why[256] = "";
     bool ok = false;
     Rccl()
     {
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // The ROCm installation's own RCCL first, by absolute path: a host program that has loaded PyTorch has that
+        // wheel's bundled librccl (another ROCm release) first in line for the bare soname, and this library is built
+        // against the installation's HIP. $ZMLS_RCCL_LIBRARY overrides; the bare sonames remain as the fallback.
+        const char *names[] = {getenv("ZMLS_RCCL_LIBRARY"), "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
         for (const char *n : names) {
+            if (!n || !*n) continue;
             handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (handle) break;
         }
@@ -51,7 +57,10 @@ struct Rccl {
         ZSYM(ReduceScatter, "ncclReduceScatter")
         ZSYM(AllGather, "ncclAllGather")
         ZSYM(GetErrorString, "ncclGetErrorString")
+        ZSYM(GetVersion, "ncclGetVersion")
 #undef ZSYM
+        Dl_info di;
+        if (dladdr((void *)GetUniqueId, &di) && di.dli_fname) snprintf(path, sizeof path, "%s", di.dli_fname);
         ok = true;
     }
 };
@@ -227,6 +236,15 @@ int zmls_comm_create_loopback(zmls_comm **out, void *hub, int rank, int device)
         return rc;
     }
     *out = c;
+    return ZMLS_OK;
+}
+
+int zmls_comm_library_info(char *path, size_t path_bytes, int *version)
+{
+    Rccl *r = rccl();
+    if (!r) return ZMLS_E_COMM;
+    if (path && path_bytes) snprintf(path, path_bytes, "%s", r->path);
+    if (version) ZNCCL(r, r->GetVersion(version));
     return ZMLS_OK;
 }
 

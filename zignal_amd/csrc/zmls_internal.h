@@ -16,10 +16,12 @@ constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr int kMaxTransformOrder = 30;
 constexpr int kMaxSequenceOrder = 32;
 constexpr int kSynthTaps = 16;
-// cache-resident schedule (api.hip::run_passes): chunk size that keeps the intermediate in the 256 MiB Infinity Cache, and
-// the largest period count it is used for by default (beyond it the capture stream dominates and everything streams)
+// cache-resident schedule (api.hip::run_passes): chunk size that keeps the intermediate in the 256 MiB Infinity Cache
+// (measured best at 256 MiB for every shape tried, profiles/r03_resident_sweep.txt: 128 MiB chunks launch too few
+// workgroups at a time, 384-512 MiB fall out of the cache). Used at every period count: the headline batch (16 periods)
+// gains as much from it as the single-period ones (13.05-13.26 against 14.2-15.3 ms on one box).
 constexpr size_t kResidentBytes = (size_t)256 << 20;
-constexpr int kResidentMaxPeriods = 2;
+constexpr int kResidentMaxPeriods = 0x7FFFFFFF;
 
 // tile configurations (geometry.h). CFG_SMALL is the general one (any channel count, any strides,
 // single-pass orders); CFG_BIG is the streaming one for wide, vector-aligned channel blocks.

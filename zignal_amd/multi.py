@@ -13,7 +13,8 @@ period-sharded (RCCL reduce-scatter over xGMI)
     followed by one division and xcorr_circular (mls.py:169-256) is linear, so each rank adds up its own
     periods, the partial sums are reduce-scattered over the channel axis, and rank q transforms channel
     block q. `PeriodSharded.impulse_device` does that through libzmls (RCCL is loaded by the library; this
-    module has no PyTorch dependency, the caller brings the 128 bootstrap bytes to every rank).
+    module has no PyTorch dependency, the caller brings the 128 bootstrap bytes to every rank:
+    `zignal_amd.rendezvous.Rendezvous.broadcast`, `file_exchange` below, MPI, anything).
 """
 import ctypes
 import os
@@ -86,15 +87,11 @@ def file_exchange(path, rank, make_id, timeout_s=120.0):
         time.sleep(0.01)
 
 
-def torch_exchange(dist, rank, make_id):
-    """Bootstrap over an initialised torch.distributed process group of CPU tensors (gloo): rank 0's id
-    is broadcast. torch is only touched here, by callers that already use it (bench.py, tests)."""
-    import torch
-    t = torch.zeros(L.COMM_ID_BYTES, dtype=torch.uint8)
-    if rank == 0:
-        t = torch.frombuffer(bytearray(make_id()), dtype=torch.uint8).clone()
-    dist.broadcast(t, src=0)
-    return bytes(t.numpy().tobytes())
+def rccl_library():
+    """(path, version code) of the librccl that libzmls loaded"""
+    buf, ver = ctypes.create_string_buffer(512), ctypes.c_int(0)
+    L.check(L.lib().zmls_comm_library_info(buf, 512, ctypes.byref(ver)))
+    return buf.value.decode(), ver.value
 
 
 def make_unique_id():
