@@ -81,6 +81,12 @@ int zmls_plan_import_table(zmls_plan *p, int which, const uint32_t *in);
  * arithmetic, another launch order). No reference counterpart. */
 int zmls_plan_set_resident(zmls_plan *p, int mode, size_t bytes, int flags);
 
+/* Tuning / tests: the pseudo-channel layout that one channel from N = 18 and up to four at N = 20..22 take by default (csrc/fwht_kernels.inc,
+ * one channel per 128-byte-row slab, the low 4 / 5 transform bits inside the row). mode -1: the library decides
+ * (default), 0: never (such batches go through the ordinary channel slabs and layout adapters), 1: whenever the order allows
+ * (N >= 6 for f64 plans, 7 for f32), whatever the channel count. No reference counterpart. */
+int zmls_plan_force_pseudo_channels(zmls_plan *p, int mode);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU test tier) */
 /* how a 2^N-point transform is split into LDS-resident passes: bits[i] for i < returned count */
 int zmls_host_pass_split(int N, int bits[4]);

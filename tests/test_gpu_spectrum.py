@@ -65,3 +65,39 @@ def test_mls_simple_response_spectrum_is_the_emphasis_free_flat_line():
     frq, mag = k.fft(window='rectangular', normalise=False, device=0)
     assert frq.shape == (mag.shape[0],) and mag.shape == ((ms._mls.L) // 2, 1)
     assert np.max(np.abs(mag[1:])) < 1e-2         # flat 0 dB away from DC
+
+
+def test_audio_fft_keeps_the_plan_of_a_shape_between_calls():
+    """Audio.fft (audio.py:678-704) used to build and destroy a hipFFT plan per call; the few most recent shapes are kept"""
+    from zignal_amd import device as dev
+    L = (1 << 12) - 1
+    x = np.random.default_rng(3).standard_normal((L, 2))
+    a = Audio(fs=48000, initialdata=x)
+    _, m1 = a.fft(window='hann', device=0)
+    sp = dev._spectra[(L, 2, 0)]
+    _, m2 = a.fft(window='hann', device=0)
+    assert dev._spectra[(L, 2, 0)] is sp and np.array_equal(m1, m2)
+    for n in range(5):                                # more shapes than are kept: the oldest is closed and dropped
+        Audio(fs=48000, initialdata=x[:100 + n]).fft(device=0)
+    assert len(dev._spectra) == dev._SPECTRA_KEPT and (L, 2, 0) not in dev._spectra and sp._h is None
+    _, m3 = a.fft(window='hann', device=0)            # ... and comes back on demand
+    assert np.array_equal(m1, m3)
+
+
+def test_a_quiet_channel_beside_a_loud_one_keeps_its_accuracy():
+    """two channels share one complex transform at odd sizes; they are level-matched by a power of two first, so that the
+    rounding error of the loud one (1e-16 x ITS peak) does not land in the quiet one's spectrum"""
+    L = (1 << 14) - 1
+    rng = np.random.default_rng(14)
+    h = rng.standard_normal((L, 3)) * np.exp(-np.arange(L) / 500.0)[:, None]
+    h[:, 1] *= 1e-10                                  # 200 dB below its partner
+    h[:, 2] *= 1e7                                    # alone in its transform
+    sp = Spectrum(L, 3, device=0)
+    for win, norm in ((None, False), ("hann", True)):
+        import scipy.signal.windows
+        w = None if win is None else scipy.signal.windows.get_window(win, Nx=L)
+        mag = sp.magnitude_db_host(h, w, norm)
+        for c in range(3):
+            _, want = mls_oracle.audio_fft(h[:, c:c + 1], 96000, win or "rectangular", norm)
+            check(mag[:, c:c + 1], want)              # 1e-12 x the channel's OWN largest bin
+    sp.close()

@@ -30,7 +30,7 @@ def test_library_host_logic_under_asan_and_ubsan(tmp_path):
     exe = str(tmp_path / "host_selftest")
     src = os.path.join(ROOT, "zignal_amd", "csrc")
     files = [os.path.join(src, f) for f in ("zmls_host.cpp", "api.hip", "lfsr.hip", "fwht_f64.hip", "fwht_f32.hip", "period_sum.hip",
-                                             "layout.hip", "static_ws.hip")]
+                                             "layout.hip", "static_ws.hip", "hostcopy.hip")]
     cmd = [HIPCC, "-O1", "-g", "-std=c++17", "--offload-arch=gfx950", "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
            "-Xarch_host", "-fno-sanitize-recover=all", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-x", "hip"] + files + \
           [os.path.join(ROOT, "tests", "native", "host_selftest.cpp"), "-o", exe]

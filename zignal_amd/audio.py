@@ -137,15 +137,12 @@ class Audio(object):
         """FFT magnitude of all channels in dB, up to fs/2: (frq, mag) as zignal/audio.py:678-704. The transform
         runs on the GPU (zmls_spectrum_*: window, hipFFT, dB); window values and the frequency axis are host work."""
         import scipy.signal.windows
-        from .device import Spectrum
-        sp = Spectrum(self.nofsamples, self.ch, device=device)
-        try:
-            rect = window in ('rectangular', 'boxcar', 'box', 'ones', 'rect')
-            win = None if rect else scipy.signal.windows.get_window(window, Nx=self.nofsamples)   # not fftsize! (audio.py:690)
-            mag = sp.magnitude_db_host(self.samples, win, normalise)
-            frq = np.fft.fftfreq(sp.fftsize, 1 / self.fs)[:int(sp.fftsize / 2)]
-        finally:
-            sp.close()
+        from .device import spectrum_for
+        sp = spectrum_for(self.nofsamples, self.ch, device=device)     # the plan of this shape is kept between calls
+        rect = window in ('rectangular', 'boxcar', 'box', 'ones', 'rect')
+        win = None if rect else scipy.signal.windows.get_window(window, Nx=self.nofsamples)   # not fftsize! (audio.py:690)
+        mag = sp.magnitude_db_host(self.samples, win, normalise)
+        frq = np.fft.fftfreq(sp.fftsize, 1 / self.fs)[:int(sp.fftsize / 2)]
         return frq, mag
 
     def plot_fft(self, plotname=None, window='hann', normalise=True, **kwargs):

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <vector>
+#include <thread>
 #include "zmls_internal.h"
 
 namespace zmls {
@@ -161,6 +162,8 @@ int build_plan(zmls_plan *p)
     // the tall tile earns its single workgroup per CU only where its 11-bit passes save a whole pass over HBM: N = 21, 22
     p->tall_npass = pass_split(p->N, p->tall_bits, kTallPassBits);
     if (!(p->npass == 3 && p->tall_npass == 2)) p->tall_npass = 0;
+    // the pseudo-channel layout of few-channel batches: the row bits N - PCB go through the passes (2 are the least a pass takes)
+    p->pc_npass = (p->N - pc_bits_of(p->dtype) >= 2) ? pass_split(p->N - pc_bits_of(p->dtype), p->pc_bits) : 0;
     if (p->npass > 1) {
         for (int c = 0; c < CFG_COUNT; ++c) {
             if (c == CFG_BIG) continue;                   // only ever used when forced: built by zmls_plan_force_tile
@@ -218,6 +221,7 @@ int zmls_plan_create(zmls_plan **out, int N, const int32_t *taps, int ntaps, int
     p->force_cfg = -1;
     p->swizzle = 1;
     p->resident_mode = -1;
+    p->force_pc = -1;
     rc = build_plan(p);
     if (rc) { free_plan_buffers(p); free(p); return rc; }
     *out = p;
@@ -298,6 +302,14 @@ int zmls_plan_force_tile(zmls_plan *p, int cfg)
     p->swizzle = (cfg >= 0 && (cfg & 0x100)) ? 0 : 1;     // +256: switch the XCD-aware block mapping off (tuning)
     p->work_layout = (cfg >= 0 && (cfg & 0x400)) ? 1 : 0; // +1024: row-major workspace (tuning)
     p->force_cfg = cfg < 0 ? -1 : (cfg & 0xFF);
+    return ZMLS_OK;
+}
+
+int zmls_plan_force_pseudo_channels(zmls_plan *p, int mode)
+{
+    if (!p || mode < -1 || mode > 1) { set_error("pseudo-channel layout: mode must be -1 (auto), 0 (off) or 1 (on)"); return ZMLS_E_ARG; }
+    if (mode > 0 && !p->pc_npass) { set_error("order %d is too small for the pseudo-channel layout", p->N); return ZMLS_E_UNSUPPORTED; }
+    p->force_pc = mode;
     return ZMLS_OK;
 }
 
@@ -403,7 +415,20 @@ int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
     }
     (void)hipFree(d);
     if (rc) return rc;
-    for (int64_t r = 1; r < repeats; ++r) memcpy(out + r * p->L, out, (size_t)p->L * 8);   // np.tile, mls.py:164
+    // np.tile, mls.py:164. The caller's array is usually fresh (numpy.empty: every page faults on first touch), so long
+    // stimuli are tiled by a few threads, each writing whole repeats of its own
+    const int64_t copies = repeats - 1;
+    const int nthr = (copies * p->L * 8 >= ((int64_t)32 << 20)) ? (int)std::min<int64_t>(4, copies) : 1;
+    auto tile = [&](int t) {
+        for (int64_t r = 1 + t; r < repeats; r += nthr) memcpy(out + r * p->L, out, (size_t)p->L * 8);
+    };
+    if (nthr == 1) tile(0);
+    else {
+        std::thread th[3];
+        for (int t = 1; t < nthr; ++t) th[t - 1] = std::thread(tile, t);
+        tile(0);
+        for (int t = 1; t < nthr; ++t) th[t - 1].join();
+    }
     return ZMLS_OK;
 }
 
@@ -477,11 +502,24 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
         if (cfg == CFG_TALL && work_bytes < slab_bytes(p, CFG_TALL)) cfg = CFG_MID;
         if (cfg == CFG_MID && work_bytes < slab_bytes(p, CFG_MID)) cfg = CFG_SMALL;
     }
+    // Few channels (the reference's own call is ONE): the pseudo-channel layout, one channel per 128-byte-row slab of
+    // 2^(N-PCB) rows, any strides and sample types (fwht_kernels.inc::row_butterflies). A caller's workspace too small for
+    // one such slab leaves the ordinary tiles to try.
+    const int PCB = pc_bits_of(p->dtype);
+    const int N_eff_pc = p->N - PCB;
+    const size_t pc_slab = p->pc_npass ? (size_t)work_rows_total(N_eff_pc) * (kVecBytes << kCfg[CFG_MID].lu) : 0;
+    const bool pc = p->pc_npass > 0 && (p->force_pc > 0 || (p->force_pc < 0 && p->force_cfg < 0 && pc_pays(p->N, n_ch))) &&
+                    (p->pc_npass == 1 || own_work || work_bytes >= pc_slab);
+    if (pc) cfg = CFG_MID;
     const TileCfg tc = kCfg[cfg];
-    const int npass = (cfg == CFG_TALL) ? p->tall_npass : p->npass;
-    const int *pass_bits = (cfg == CFG_TALL) ? p->tall_bits : p->bits;
-    const int CS = chans_per_slab(p, cfg);
+    const int N_eff = pc ? N_eff_pc : p->N;                         // transform bits the passes see
+    const int npass = pc ? p->pc_npass : (cfg == CFG_TALL) ? p->tall_npass : p->npass;
+    const int *pass_bits = pc ? p->pc_bits : (cfg == CFG_TALL) ? p->tall_bits : p->bits;
+    const int CS = pc ? 1 : chans_per_slab(p, cfg);
     const int64_t n_slabs = (n_ch + CS - 1) / CS;
+    const size_t sbytes = pc ? pc_slab : slab_bytes(p, cfg);
+    const int in_first = pc ? IN_GATHER_PC : vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM;
+    const int out_last = pc ? OUT_SCATTER_PC : vec_out ? OUT_SCATTER_VEC : OUT_SCATTER_ELEM;
 
     PassArgs a;
     memset(&a, 0, sizeof a);
@@ -492,7 +530,25 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
     a.h = d_h; a.out_row_stride = out_row_stride; a.out_ch_stride = out_ch_stride;
     a.out_scale = ldexp(1.0 / (double)p->L, -p->in_scale_log2);
 
-    if (single) {
+    if (pc && npass == 1) {
+        // the whole transform of 2^LT channels per workgroup, in one launch
+        const int K = pass_bits[0];
+        a.single = 1; a.b = 0; a.n_macro = 1; a.ch_first = 0;
+        a.scatter = p->d_scatter_nat;
+        a.n_slab_groups = (uint32_t)((n_ch + (1 << log2_tiles(K, tc)) - 1) >> log2_tiles(K, tc));
+        if (ev) ZHIP(hipEventRecord(ev[0], st));
+        rc = launch(cfg, K, IN_GATHER_PC, OUT_SCATTER_PC, a, st);
+        if (rc) return rc;
+        if (ev) {
+            float ms = 0.f;
+            ZHIP(hipEventRecord(ev[1], st));
+            ZHIP(hipEventSynchronize(ev[1]));
+            ZHIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            pass_ms[0] += ms;
+        }
+        return ZMLS_OK;
+    }
+    if (single && !pc) {
         const int K = p->bits[0];
         const int LT = log2_tiles(K, tc);
         a.single = 1; a.b = 0; a.n_macro = 1;
@@ -529,14 +585,14 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
         return ZMLS_OK;
     }
 
-    int64_t cap = (int64_t)(work_bytes / slab_bytes(p, cfg));
+    int64_t cap = (int64_t)(work_bytes / sbytes);
     if (cap < 1) {
-        if (own_work) set_error("plan workspace (%zu bytes) holds no channel slab (%zu bytes each): call zmls_plan_reserve first", work_bytes, slab_bytes(p, cfg));
-        else set_error("order %d needs %zu bytes of workspace for one channel slab; the caller's workspace holds %zu", p->N, slab_bytes(p, cfg), work_bytes);
+        if (own_work) set_error("plan workspace (%zu bytes) holds no channel slab (%zu bytes each): call zmls_plan_reserve first", work_bytes, sbytes);
+        else set_error("order %d needs %zu bytes of workspace for one channel slab; the caller's workspace holds %zu", p->N, sbytes, work_bytes);
         return ZMLS_E_WORKSPACE;
     }
     a.work = work;
-    a.scatter = p->d_scatter_perm[cfg];
+    a.scatter = pc ? p->d_scatter_nat : p->d_scatter_perm[cfg];
     if (!a.scatter) { set_error("tile configuration %d has not been prepared for this plan", cfg); return ZMLS_E_UNSUPPORTED; }
 
     // ---- the cache-resident schedule (round 3). With one or two averaged periods every pass moves the whole batch through
@@ -548,7 +604,6 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
     // are closed under the low K0+K1 bits, so they run chunk by chunk over ranges of the top bits (contiguous macro tiles
     // in both), the second in place; the third pass then runs over everything from HBM. With many periods the capture
     // stream is what counts and the non-temporal pair of round 2 stays (fwht_kernels.inc).
-    const size_t sbytes = slab_bytes(p, cfg);
     const size_t budget = p->resident_bytes ? p->resident_bytes : kResidentBytes;
     const bool want_resident = p->work_layout == 0 && (p->resident_mode > 0 || (p->resident_mode < 0 && periods <= kResidentMaxPeriods));
     const bool resident2 = want_resident && npass == 2 && sbytes <= budget;       // (the placement probe's lone gather pass runs in the same chunks)
@@ -582,7 +637,7 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
         a.n_slab_groups = ns;
         a.macro_first = 0;
         a.slab_fastest = p->work_layout;
-        a.work_slab_stride = p->work_layout ? U : work_rows_total(p->N) * U;
+        a.work_slab_stride = p->work_layout ? U : work_rows_total(N_eff) * U;
         a.work_row_stride = p->work_layout ? (uint64_t)ns * U : U;
         // two-pass orders on two lanes: chunk k runs on lane k & 1 in that lane's half of the workspace
         hipStream_t gs = st;
@@ -617,7 +672,7 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
                     a.b = 0; a.macro_first = t0 << (K1 - LT0); a.n_macro = nt << (K1 - LT0);
                     a.swz_group = swizzle_of(0, a.n_macro, nsub);
                     a.work_keep_ld = 0; a.work_keep_st = 1;
-                    rc = launch(cfg, K0, vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM, OUT_WORK, a, cs);
+                    rc = launch(cfg, K0, in_first, OUT_WORK, a, cs);
                     if (rc) return rc;
                     a.b = K0; a.macro_first = t0 << (K0 - LT1); a.n_macro = nt << (K0 - LT1);
                     a.swz_group = swizzle_of(1, a.n_macro, nsub);
@@ -639,9 +694,9 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
             const int K = pass_bits[i];
             const int LT = log2_tiles(K, tc);
             a.b = b;
-            a.n_macro = (uint32_t)(1u << (p->N - K - LT));
-            const int inm = (i == 0) ? (vec_in ? IN_GATHER_VEC : IN_GATHER_ELEM) : IN_WORK;
-            const int outm = (i == npass - 1) ? (vec_out ? OUT_SCATTER_VEC : OUT_SCATTER_ELEM) : OUT_WORK;
+            a.n_macro = (uint32_t)(1u << (N_eff - K - LT));
+            const int inm = (i == 0) ? in_first : IN_WORK;
+            const int outm = (i == npass - 1) ? out_last : OUT_WORK;
             a.swz_group = swizzle_of(i, a.n_macro, ns);
             a.work_keep_st = resident2 ? 1 : 0;
             a.work_keep_ld = (resident2 && !(p->resident_flags & 2)) ? 1 : 0;
@@ -711,6 +766,23 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
     const bool vec_in = in_dtype == p->dtype && ch_stride == 1 && (row_stride * (int64_t)ts) % kVecBytes == 0 &&
                         ((uintptr_t)d_x % kVecBytes) == 0 && n_ch % E == 0;
     const bool vec_out = out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 && ((uintptr_t)d_h % kVecBytes) == 0 && n_ch % E == 0;
+    if (p->pc_npass > 0 && !gather_pass_only && (p->force_pc > 0 || (p->force_pc < 0 && p->force_cfg < 0 && pc_pays(p->N, n_ch)))) {
+        // Few channels - the reference's own call is one - take the pseudo-channel layout (run_passes), which reads and writes
+        // any strides and sample types element by element: no layout adapters. Its 8-byte gathers want ONE period to gather
+        // from, so with staging the periods are added up first, in time order and period order (coalesced; the same sums the
+        // gather would form), and the gather divides by their count.
+        const void *src = d_x;
+        int src_dtype = in_dtype, src_skip = skip_periods;
+        int64_t src_periods = periods, src_rs = row_stride, src_cs = ch_stride;
+        if (periods > 1 && stage[0] && stage_bytes >= (size_t)p->L * (size_t)n_ch * ts) {
+            ZDEVICE(p->device);
+            int rc = launch_period_sum(d_x, in_dtype, p->dtype, p->L, periods, skip_periods, row_stride, ch_stride, 1, 0, 0, n_ch, n_ch, stage[0], st);
+            if (rc) return rc;
+            src = stage[0]; src_dtype = p->dtype; src_skip = 0; src_periods = 1; src_rs = n_ch; src_cs = 1;
+        }
+        return run_passes(p, src, src_dtype, src_periods, src_skip, divisor, n_ch, src_rs, src_cs, d_h, out_row_stride, out_ch_stride, st, ev,
+                          pass_ms, 0, work, work_bytes);
+    }
     const int64_t per_ch = p->L * (int64_t)ts;                                    // staging bytes per channel
     int64_t cc = (int64_t)(stage_bytes / (size_t)per_ch) / E * E;                 // channels a staging array holds
     const bool in_cm = multi && !vec_in && row_stride == 1 && cc >= E;
@@ -858,19 +930,20 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
     rc = host_call_buffer(p, 0, in_span, &d_x, &free_x);
     if (!rc) rc = host_call_buffer(p, 1, out_span, &d_h, &free_h);
     if (!rc) {
-        hipError_t e;
-        if (stacked) e = hipMemcpy2D(d_x, (size_t)rows * is, x_from, (size_t)ch_stride * is, (size_t)rows * is, (size_t)n_ch, hipMemcpyHostToDevice);
-        else e = hipMemcpy(d_x, x_from, in_span, hipMemcpyHostToDevice);
+        // large captures go up in chunks through pinned bounce buffers, several at a time (hostcopy.hip)
+        if (stacked && (size_t)rows * is < ((size_t)8 << 20)) {
+            hipError_t e = hipMemcpy2D(d_x, (size_t)rows * is, x_from, (size_t)ch_stride * is, (size_t)rows * is, (size_t)n_ch, hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = hip_fail(e, "impulse_host upload");
+        } else if (stacked) {
+            for (int64_t c = 0; c < n_ch && !rc; ++c)
+                rc = host_copy(p->device, (char *)d_x + (size_t)c * (size_t)rows * is, (void *)(x_from + (size_t)c * (size_t)ch_stride * is), (size_t)rows * is, true);
+        } else rc = host_copy(p->device, d_x, (void *)x_from, in_span, true);
         // a strided view of a larger array: keep the bytes between the elements we own
-        if (e == hipSuccess && !out_dense) e = hipMemcpy(d_h, h, out_span, hipMemcpyHostToDevice);
-        if (e != hipSuccess) rc = hip_fail(e, "impulse_host upload");
+        if (!rc && !out_dense) rc = host_copy(p->device, d_h, h, out_span, true);
     }
     if (!rc) rc = impulse_device_core(p, d_x, in_dtype, periods, 0, periods, n_ch, row_stride, dev_cs, d_h, out_row_stride, out_ch_stride,
                                       nullptr, nullptr, nullptr, 0);
-    if (!rc) {
-        hipError_t e = hipMemcpy(h, d_h, out_span, hipMemcpyDeviceToHost);      // null stream: ordered after the kernels
-        if (e != hipSuccess) rc = hip_fail(e, "impulse_host download");
-    }
+    if (!rc) rc = host_copy(p->device, d_h, h, out_span, false);                 // ordered after the kernels on the null stream
     if (free_x && d_x) (void)hipFree(d_x);
     if (free_h && d_h) (void)hipFree(d_h);
     return rc;
@@ -981,8 +1054,8 @@ int zmls_average_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
     void *d_x = nullptr, *d_o = nullptr;
     hipError_t e = hipMalloc(&d_x, in_span);
     if (e == hipSuccess) e = hipMalloc(&d_o, out_bytes);
-    if (e == hipSuccess) e = hipMemcpy(d_x, x, in_span, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = hip_fail(e, "average_host staging");
+    if (!rc) rc = host_copy(p->device, d_x, (void *)x, in_span, true);
     if (!rc) rc = launch_average(d_x, in_dtype, p->L, n_rows / p->L - 1, n_ch, row_stride, ch_stride, d_o, 0);
     if (!rc) {
         e = hipMemcpy(out, d_o, out_bytes, hipMemcpyDeviceToHost);
@@ -1049,15 +1122,13 @@ int zmls_dev_upload(int device, void *d_dst, const void *src, size_t bytes)
 {
     ZDEVICE(device);
     int rc = ZMLS_OK;
-    ZHIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
-    return ZMLS_OK;
+    return host_copy(device, d_dst, (void *)src, bytes, true);
 }
 int zmls_dev_download(int device, void *dst, const void *d_src, size_t bytes)
 {
     ZDEVICE(device);
     int rc = ZMLS_OK;
-    ZHIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
-    return ZMLS_OK;
+    return host_copy(device, (void *)d_src, dst, bytes, false);
 }
 int zmls_dev_memset(int device, void *d_ptr, int value, size_t bytes)
 {

@@ -853,14 +853,11 @@ int zmls_iir_host(zmls_iir *f, const void *x, int in_dtype, int64_t n_rows, int6
     double *d_y = nullptr;
     hipError_t e = hipMalloc(&d_x, in_span);
     if (e == hipSuccess) e = hipMalloc((void **)&d_y, out_bytes);
-    if (e == hipSuccess) e = hipMemcpy(d_x, x, in_span, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = hip_fail(e, "filter staging");
+    if (!rc) rc = host_copy(f->device, d_x, (void *)x, in_span, true);
     // the result keeps the layout class of the input: (n_rows, n_ch) C-contiguous
     if (!rc) rc = zmls_iir_device(f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_y, n_ch, 1, nullptr);
-    if (!rc) {
-        e = hipMemcpy(y, d_y, out_bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = hip_fail(e, "filter download");
-    }
+    if (!rc) rc = host_copy(f->device, d_y, y, out_bytes, false);
     if (d_x) (void)hipFree(d_x);
     if (d_y) (void)hipFree(d_y);
     return rc;

@@ -163,8 +163,18 @@ __global__ void __launch_bounds__(256) period_sum_elem_kernel(const void *__rest
         const int64_t c = r - q * block_ch;
         const int64_t ch = q * block_ch_stride + ch_first + c;
         T acc = (T)0;
-        for (int p = 0; p < (ch < ch_limit ? periods : 0); ++p)
-            acc += sum_load<T>(x, ((int64_t)(skip + p) * L + j) * row_stride + ch * ch_stride, in_dtype);
+        const int np = ch < ch_limit ? periods : 0;
+        const int64_t first = ((int64_t)skip * L + j) * row_stride + ch * ch_stride, pstep = L * row_stride;
+        constexpr int PU = 4;                               // periods loaded back to back (one 8-byte load in flight per lane is latency-bound)
+        int p = 0;
+        for (; p + PU <= np; p += PU) {
+            T t[PU];
+#pragma unroll
+            for (int i = 0; i < PU; ++i) t[i] = sum_load<T>(x, first + (int64_t)(p + i) * pstep, in_dtype);
+#pragma unroll
+            for (int i = 0; i < PU; ++i) acc += t[i];       // period order, as numpy adds the rows
+        }
+        for (; p < np; ++p) acc += sum_load<T>(x, first + (int64_t)p * pstep, in_dtype);
         out[(q * L + j) * block_ch + c] = acc;
     }
 }

@@ -16,6 +16,16 @@ constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr int kMaxTransformOrder = 30;
 constexpr int kMaxSequenceOrder = 32;
 constexpr int kSynthTaps = 16;
+// Which batches take the pseudo-channel layout on their own (one channel per slab, fwht_kernels.inc). Measured, device-resident
+// f64 captures, ordinary slabs against the layout (tools/single_channel_timing.py, profiles/r03_single_channel.txt): ONE channel - the
+// reference's call - breaks even at N = 18 (0.049 ms both) and wins from there (N = 20 x 17 periods 0.371 -> 0.082 ms, N = 24 x 2
+// 2.95 -> 0.60 ms); below, both are two 10 us launches and the ordinary grid has more workgroups (N = 16: 0.024 against 0.036 ms).
+// Two to four channels win at N = 20..22 only (4 channels, N = 20 x 17: 0.41 -> 0.18 ms): above, one period of the capture no longer
+// fits the caches and the 8-byte gathers of the layout fetch a whole line per sample, where the ordinary slab reads all channels of
+// a row in one piece.
+constexpr int kPcMaxChannels = 4;
+constexpr bool pc_pays(int N, int64_t n_ch) { return (n_ch == 1 && N >= 18) || (n_ch <= kPcMaxChannels && N >= 20 && N <= 22); }
+constexpr int pc_bits_of(int dtype) { return dtype == ZMLS_F64 ? 4 : 5; }       // log2 of the elements of a 128-byte row
 // cache-resident schedule (api.hip::run_passes): chunk size that keeps the intermediate in the 256 MiB Infinity Cache
 // (measured best at 256 MiB for every shape tried, profiles/r03_resident_sweep.txt: 128 MiB chunks launch too few
 // workgroups at a time, 384-512 MiB fall out of the cache). Used at every period count: the headline batch (16 periods)
@@ -69,8 +79,10 @@ uint32_t host_fib_state_at(int N, uint32_t G, const JumpTables &jt, uint64_t ste
 bool period_is_maximal(int N, const JumpTables &jt);                  // host; used where no tables are built
 
 // ---- pass launch description
-enum InMode { IN_WORK = 0, IN_GATHER_VEC = 1, IN_GATHER_ELEM = 2 };
-enum OutMode { OUT_WORK = 0, OUT_SCATTER_VEC = 1, OUT_SCATTER_ELEM = 2 };
+// IN_GATHER_PC / OUT_SCATTER_PC: the pseudo-channel layout of a single channel (fwht_kernels.inc): the low 4 (f64) or 5 (f32)
+// bits of the transform index ride in the positions that adjacent channels have in the other modes
+enum InMode { IN_WORK = 0, IN_GATHER_VEC = 1, IN_GATHER_ELEM = 2, IN_GATHER_PC = 3 };
+enum OutMode { OUT_WORK = 0, OUT_SCATTER_VEC = 1, OUT_SCATTER_ELEM = 2, OUT_SCATTER_PC = 3 };
 
 struct PassArgs {
     int N;                    // transform order
@@ -149,6 +161,8 @@ struct DeviceScope {
     ::zmls::DeviceScope ZCAT(zscope_, __LINE__)(dev);         \
     if (ZCAT(zscope_, __LINE__).rc) return ZCAT(zscope_, __LINE__).rc
 hipError_t settled_malloc(void **ptr, size_t bytes);
+// pageable host memory <-> device memory, large copies in chunks through pinned bounce buffers on several streams (hostcopy.hip)
+int host_copy(int device, void *d_ptr, void *h_ptr, size_t bytes, bool to_device);
 
 int launch_pass_f64(int cfg, int K, int inm, int outm, const PassArgs &a, hipStream_t st);
 int launch_pass_f32(int cfg, int K, int inm, int outm, const PassArgs &a, hipStream_t st);
@@ -189,6 +203,9 @@ struct zmls_plan {
     int bits[4];
     int tall_npass;               // pass split of the tall tile (11 bits per pass), 0 when it saves no pass
     int tall_bits[4];
+    int pc_npass;                 // pass split of the N - 4 (f64) / N - 5 (f32) row bits of the pseudo-channel layout, 0 when the order is too small for it
+    int pc_bits[4];
+    int force_pc;                 // -1: few-channel batches take the pseudo-channel layout, 0: never, 1: whenever it applies (tests, tuning)
     uint32_t s0;                  // Fibonacci state at n = 0 (first N sequence bits)
     int maximal;                  // the register's period is 2^N - 1 (else: the sequence is generated, the transform refused)
     uint32_t *d_bits;             // packed sequence bits, n_words uint32

@@ -89,6 +89,10 @@ class Plan:
         """-1 auto, 0 small, 1 big, 2 mid, 3 tall tile (tests / tuning)"""
         L.check(L.lib().zmls_plan_force_tile(self._h, int(cfg)))
 
+    def force_pseudo_channels(self, mode=-1):
+        """pseudo-channel layout of few-channel batches (tests / tuning): -1 the library decides, 0 never, 1 whenever the order allows"""
+        L.check(L.lib().zmls_plan_force_pseudo_channels(self._h, int(mode)))
+
     def set_resident(self, mode=-1, nbytes=0, flags=0):
         """cache-resident schedule (tests / tuning): -1 the library decides, 0 off, 1 on; chunk bytes (0 = built-in); flags"""
         L.check(L.lib().zmls_plan_set_resident(self._h, int(mode), int(nbytes), int(flags)))
@@ -352,6 +356,25 @@ class Spectrum:
 
     def magnitude_db_device(self, d_h, row_stride, ch_stride, d_window, normalise, d_mag, stream=None):
         L.check(L.lib().zmls_spectrum_device(self._h, d_h, int(row_stride), int(ch_stride), d_window, int(bool(normalise)), d_mag, stream))
+
+
+_spectra = {}                  # (n_samples, n_ch, device) -> Spectrum, most recently used last
+_SPECTRA_KEPT = 4
+
+
+def spectrum_for(n_samples, n_ch=1, device=None):
+    """The Spectrum (hipFFT plan + device buffers) for this shape, kept between calls: building a Bluestein plan for L = 2^N - 1
+    points costs more than the transform it then runs (Audio.fft used to build and destroy one per call). The few most recently
+    used shapes stay; the one that falls out is closed."""
+    dev = L.default_device() if device is None else int(device)
+    key = (int(n_samples), int(n_ch), dev)
+    sp = _spectra.pop(key, None)
+    if sp is None or getattr(sp, "_h", None) is None:
+        sp = Spectrum(key[0], key[1], device=dev)
+    _spectra[key] = sp
+    while len(_spectra) > _SPECTRA_KEPT:
+        _spectra.pop(next(iter(_spectra))).close()
+    return sp
 
 
 def sync(device=0):

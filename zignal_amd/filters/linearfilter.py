@@ -1,8 +1,10 @@
 """The slice of zignal's `Filter` that the MLS emphasis / de-emphasis step uses
 (zignal/filters/linearfilter.py:28-143): coefficient holder, `filter_samples`
 (= scipy.signal.lfilter along axis 0) and the minimum-phase test MLS asserts on
-(zignal/measure/mls.py:365-369). Runs on the host; moving it onto the device is
-the first "next" row of SURVEY.md §8(f).
+(zignal/measure/mls.py:365-369). `filter_samples` runs on the device (csrc/iir.hip:
+lfilter's transposed-direct-form-II recurrence, block-parallel) for
+orders up to 8, which covers every filter zignal ships; the MLS classes call the same
+kernels directly (zignal_amd/measure/mls.py). The pole/zero tests are host work.
 """
 import numpy as np
 import scipy.signal
@@ -29,7 +31,15 @@ class Filter(object):
         self._A = self._A / a0
 
     def filter_samples(self, samples):
-        return scipy.signal.lfilter(self._B, self._A, samples, axis=0)
+        """scipy.signal.lfilter(B, A, samples, axis=0) (zignal/filters/linearfilter.py:62-63), computed on the GPU.
+        Like every compute call of this package it fails loudly without the HIP library or a GPU; orders above 8
+        (none in zignal) are refused by the library."""
+        from ..device import IirFilter
+        f = IirFilter(self._B, self._A)
+        try:
+            return f.filter_host(np.asarray(samples))
+        finally:
+            f.close()
 
     def _zeros_poles(self):
         z, p, _ = scipy.signal.tf2zpk(self._B, self._A)
