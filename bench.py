@@ -244,7 +244,7 @@ def profiled_traffic(config):
             c = d["bench_line_of_the_traced_run"]["config"]
             if all(c.get(k) == config.get(k) for k in ("order", "channels_per_gpu", "averaged_periods", "layout", "mode")) and \
                     d["bench_line_of_the_traced_run"]["dtype"] == config["dtype"]:
-                t = sum(k["hbm_traffic_bytes_per_launch"] for k in d["kernels"])
+                t = d.get("hbm_traffic_bytes_per_step") or sum(k["hbm_traffic_bytes_per_launch"] for k in d["kernels"])
                 best = (t, "profiles/" + name)
         except (KeyError, ValueError, OSError, TypeError):
             continue
@@ -636,6 +636,8 @@ def main():
             "alg_bytes_per_step": alg_bytes, "kernel_ms_per_step": pipeline_ms,
             "pass_ms": [float(v) for v in pass_ms],
             "per_kernel": per_kernel(pass_ms, Ravg, L, es, C),
+            # the cache-resident schedule runs one step as several chunk launches of each pass kernel (csrc/api.hip::run_passes)
+            "launches_per_step": dict(zip(("first_pass", "middle_passes", "last_pass"), plan.last_launches())),
         },
         "plan_build_s": plan_build_s,
         # the spread over the ranks (placement plateaus differ from GPU to GPU: DESIGN.md §3): wall time per step of every

@@ -125,7 +125,8 @@ int zmls_impulse_device(zmls_plan *p, const void *d_x, int in_dtype, int64_t n_r
  * runs on holds it until the process ends) instead of the workspace zmls_plan_reserve allocates, so a plan that
  * never reserved anything can be used; the batch runs in chunks of as many channel slabs as the array holds.
  * Orders above ZMLS_STATIC_MAX_ORDER (one slab of the intermediate no longer fits) are refused with
- * ZMLS_E_WORKSPACE. Captures in any layout and input type are accepted; those that are not 16-byte-aligned
+ * ZMLS_E_WORKSPACE - except a single channel, the reference's own call shape, which takes the sixteen times smaller
+ * slabs of the pseudo-channel layout and is served up to order 24. Captures in any layout and input type are accepted; those that are not 16-byte-aligned
  * (frames, channels) arrays of the plan's dtype go one element per lane (the layout adapters need allocated
  * staging). Calls neither hipMalloc/hipFree nor synchronises. All calls on one GPU share the array: calls that
  * overlap on one GPU (two streams, two threads) race; calls in stream order do not. */
@@ -238,7 +239,8 @@ int zmls_iir_destroy(zmls_iir *f);
 /* scratch for signals of up to n_rows frames x n_ch channels (allocates; outside timed regions) */
 int zmls_iir_reserve(zmls_iir *f, int64_t n_rows, int64_t n_ch);
 /* y (float64, any strides; may be x itself when x is float64 with the same strides) = lfilter(b, a, x) along frames.
- * Enqueues three kernels on hip_stream; never allocates or synchronises. */
+ * Enqueues three to five kernels on hip_stream (two sweeps over the signal and the start-state assembly between them:
+ * one kernel up to 16 chunks, three beyond); never allocates or synchronises. */
 int zmls_iir_device(zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
                     int64_t ch_stride, double *d_y, int64_t out_row_stride, int64_t out_ch_stride, void *hip_stream);
 /* De-emphasis and impulse response in one: replaces MLS.apply_deemphasis (mls.py:401-407) followed by get_impulse

@@ -87,6 +87,20 @@ int zmls_plan_set_resident(zmls_plan *p, int mode, size_t bytes, int flags);
  * (N >= 6 for f64 plans, 7 for f32), whatever the channel count. No reference counterpart. */
 int zmls_plan_force_pseudo_channels(zmls_plan *p, int mode);
 
+/* Tuning / tests: the filter's sweeps run over segments of the time axis of about `bytes` bytes of signal (all channels), so
+ * that the second sweep of a segment finds in the 256 MiB Infinity Cache what the first sweep read; the filter state is carried
+ * from segment to segment on the device. 0: one segment; (size_t)-1: the library's own choice (default) - which is one segment: segments measured 14-28 % slower
+ * (profiles/r03_iir_segments.txt), the option stays for tuning on other parts.
+ * Same chunks and per-sample arithmetic either way; the chunk start states are put together segment by segment instead of in one
+ * scan over the whole signal, so outputs of different segment sizes agree to rounding, and one size gives the same bits every time.
+ * No reference counterpart. */
+int zmls_iir_set_segment(zmls_iir *f, size_t bytes);
+
+/* Profiling: how many kernels the most recent impulse call on this plan launched, by kind - out[0] first (gather) pass, out[1]
+ * middle passes, out[2] last (scatter) pass. The cache-resident schedule runs a step as many chunk launches; a profile's
+ * per-launch counters times these counts are the step's (tools/summarize_profile.py). No reference counterpart. */
+int zmls_plan_last_launches(const zmls_plan *p, int32_t out[3]);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU test tier) */
 /* how a 2^N-point transform is split into LDS-resident passes: bits[i] for i < returned count */
 int zmls_host_pass_split(int N, int bits[4]);

@@ -252,3 +252,44 @@ def test_mls_simple_short_orders_against_reference_goldens():
         got = ms.get_impulse(x)
         assert got.samples.shape == arrays[c["id"] + "_ir"].shape
         assert rel_err(got.samples, arrays[c["id"] + "_ir"]) <= TOL, c
+
+
+@pytest.mark.parametrize("shape,layout", [((1 << 20, 1), "time"), ((100003, 16), "frames"), ((40000, 37), "frames"), ((1 << 17, 3), "stacked"), ((700, 5), "frames")])
+def test_segments_of_the_time_axis_carry_the_filter_state(shape, layout):
+    """round 3: the two sweeps run segment by segment so that the second one reads from the Infinity Cache; the state after a
+    segment's last chunk is the next one's initial state (iir_carry_kernel). Every segment size must give lfilter's output
+    (to 1e-12 x peak), the same bits every time, in place as well."""
+    rng = np.random.default_rng(shape[0] % 9973)
+    n, C = shape
+    x = rng.standard_normal(shape)
+    for order in (2, 5, 8):
+        B, A = stable_filter(order, rng) if order != 2 else RBJ(filtertype="lowshelf", gaindb=12, f0=60, Q=0.707, fs=96000).get_coefficients()
+        f = IirFilter(B, A, device=0)
+        f.reserve(n, C)
+        host = np.ascontiguousarray(x.T) if layout == "stacked" else x
+        rs, cs = (1, n) if layout == "stacked" else (C, 1)
+        dx = DeviceBuffer(x.nbytes).upload(host)
+        dy = DeviceBuffer(x.nbytes)
+        want = scipy.signal.lfilter(B, A, x, axis=0)
+
+        def run(seg, src=None):
+            f.set_segment(seg)
+            dy.fill(0xFF)
+            f.filter_device(dx.ptr, _lib.ZMLS_F64, n, C, rs, cs, dy.ptr, rs, cs)
+            sync(0)
+            out = dy.download(host.shape, np.float64)
+            return out.T if layout == "stacked" else out
+
+        whole = run(0)
+        assert rel_err(whole, want) <= TOL
+        for seg in (None, 1, 8192 * 8 * 3, n * C * 8 // 3, n * C * 8 - 8):      # built-in; smallest there is; three chunks of one channel; thirds; almost all
+            got = run(seg)
+            assert np.isfinite(got).all() and rel_err(got, want) <= TOL, (order, seg, rel_err(got, want))
+            assert np.array_equal(run(seg), got), "same segment size, different bits"
+        f.set_segment(n * C * 8 // 3)
+        one = run(n * C * 8 // 3)
+        f.filter_device(dx.ptr, _lib.ZMLS_F64, n, C, rs, cs, dx.ptr, rs, cs)          # in place
+        sync(0)
+        got = dx.download(host.shape, np.float64)
+        assert np.array_equal(got.T if layout == "stacked" else got, one)
+        dx.free(); dy.free(); f.close()

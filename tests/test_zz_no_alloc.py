@@ -61,6 +61,55 @@ def test_static_entry_point_matches_impulse_device_twice_in_a_row(N, C1, R1, C2,
     ref_plan.close()
 
 
+@pytest.mark.parametrize("N,C,tile", [(21, 16, 0), (20, 32, 0), (21, 8, -1)])
+def test_wide_tiles_give_way_to_the_narrow_one_when_their_slab_does_not_fit(N, C, tile):
+    """N = 21: a 128-byte-row slab (mid / tall tile) is 268 MB against the 144 MiB array, so the batch runs on the small
+    tile, one 64-byte-row slab per chunk, with vector access (api.hip::run_passes, the fallback for caller workspaces).
+    Held bit for bit to zmls_impulse_device on the small tile, and to the oracle."""
+    taps = TAPS[N][0]
+    L = (1 << N) - 1
+    p = Plan(N, taps, device=0)
+    ref_plan = Plan(N, taps, device=0)
+    ref_plan.force_tile(0)
+    ref_plan.reserve(C)
+    if tile >= 0:
+        p.force_tile(tile)
+    x = np.random.default_rng(N + C).standard_normal((2 * L, C))
+    got, want = _both(p, ref_plan, x, C)
+    assert np.array_equal(got, want), "rel %.3e" % rel_err(got, want)
+    for c in (0, C - 1):
+        assert rel_err(got[:, c], oracle_ir(N, taps, np.ascontiguousarray(x[:, c:c + 1]))) <= TOL64
+    assert p.info()["workspace_bytes"] == 0
+    p.close()
+    ref_plan.close()
+
+
+def test_one_channel_is_served_beyond_the_order_limit_through_the_pseudo_channel_layout():
+    """the reference's own call shape: one channel of N = 22 or 24 takes slabs a sixteenth of the ordinary ones"""
+    for N in (22, 24):
+        taps = TAPS[N][0]
+        L = (1 << N) - 1
+        p = Plan(N, taps, device=0)
+        ref_plan = Plan(N, taps, device=0)
+        ref_plan.reserve(1)
+        d_x, d_a, d_b = DeviceBuffer(2 * L * 8), DeviceBuffer(L * 8), DeviceBuffer(L * 8)
+        p.synth_device(d_x.ptr, _lib.ZMLS_F64, 2, 1, 1, 1, seed=5, sigma=1e-3)
+        _lib.check(_static(p, d_x.ptr, _lib.ZMLS_F64, 2 * L, 1, 1, 1, d_a.ptr, 1, 1))
+        ref_plan.impulse_device(d_x.ptr, _lib.ZMLS_F64, 2 * L, 1, 1, 1, d_b.ptr, 1, 1)
+        sync(0)
+        got = d_a.download((L,), np.float64)
+        assert np.array_equal(got, d_b.download((L,), np.float64))
+        g, d = p.synth_system(0, 5)
+        exp = np.full(L, -g.sum() / L)
+        exp[(d + np.arange(16)) % L] += g * (1.0 + 1.0 / L)
+        assert np.max(np.abs(got - exp)) <= 1e-4
+        assert p.info()["workspace_bytes"] == 0
+        for b in (d_x, d_a, d_b):
+            b.free()
+        p.close()
+        ref_plan.close()
+
+
 def test_static_entry_point_under_global_stream_capture():
     """Capture in global mode is invalidated by any allocation, free or synchronisation on any thread."""
     h = ctypes.CDLL("libamdhip64.so")
@@ -105,6 +154,7 @@ def test_static_entry_point_under_global_stream_capture():
 def test_static_entry_point_refuses_orders_beyond_its_array():
     N = 22                                       # one 64-byte-row slab of the intermediate is 268 MB > 144 MiB
     p = Plan(N, TAPS[N][0], device=0)
+    p.force_pseudo_channels(0)                   # (two channels of N = 22 would otherwise take the pseudo-channel layout, which fits)
     L = p.L
     d_x, d_h = DeviceBuffer(2 * L * 2 * 8), DeviceBuffer(L * 2 * 8)
     d_x.fill(0)

@@ -21,6 +21,8 @@ def timed(fn, reps=5):
 
 B, A = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=96000).get_coefficients()
 f = IirFilter(A, B, device=0)
+if os.environ.get("SEGMENT_MIB"):
+    f.set_segment(int(os.environ["SEGMENT_MIB"]) << 20)       # A/B runs: 0 = one segment, else MiB of signal per segment of the time axis
 for n, C, rs, cs, name in ((17 * (2**20 - 1), 1, 1, 1, "one channel, 17 periods of N=20"),
                            (2 * (2**20 - 1), 512, 512, 1, "(2L, 512) frames x channels"),
                            (17 * (2**20 - 1), 64, 64, 1, "(17L, 64) frames x channels"),

@@ -61,7 +61,21 @@ for k, st in kernels.items():
     if "GRBM_GUI_ACTIVE" in c:
         d["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8 / (st["avg_ms"] * 1e-3) / 1e9
     out["kernels"].append(d)
+# one step = launches_per_step launches of each pass kernel (the cache-resident schedule runs a step chunk by chunk); the kind
+# of a kernel is in its template arguments: <T, K, LOGV, RB, LU, LLDS, in mode, out mode, single> with mode 0 = workspace
+lps = bench.get("roofline", {}).get("launches_per_step")
+if lps and all("hbm_traffic_bytes_per_launch" in d for d in out["kernels"]):
+    total = 0.0
+    for d in out["kernels"]:
+        args = d["name"][d["name"].index("<") + 1:d["name"].rindex(">")].split(",")
+        inm, outm = int(args[6]), int(args[7])
+        kind = "first_pass" if inm != 0 else "middle_passes" if outm == 0 else "last_pass"
+        d["kind"], d["launches_per_step"] = kind, lps[kind]
+        total += d["hbm_traffic_bytes_per_launch"] * lps[kind]
+    out["hbm_traffic_bytes_per_step"] = total
 json.dump(out, open("profiles/%s_summary.json" % tag, "w"), indent=1)
+if "hbm_traffic_bytes_per_step" in out:
+    print("HBM traffic per step: %.2f GB" % (out["hbm_traffic_bytes_per_step"] / 1e9))
 for d in out["kernels"]:
     print(d["name"][:90])
     print("   avg %.3f ms  traffic %.2f GB (%.0f GB/s)  lds conflicts %.4f  valu %.3f  wait %.3f  l2hit %.3f  clk %.2f GHz" % (

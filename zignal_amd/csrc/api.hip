@@ -305,6 +305,13 @@ int zmls_plan_force_tile(zmls_plan *p, int cfg)
     return ZMLS_OK;
 }
 
+int zmls_plan_last_launches(const zmls_plan *p, int32_t out[3])
+{
+    if (!p || !out) { set_error("null argument"); return ZMLS_E_ARG; }
+    for (int i = 0; i < 3; ++i) out[i] = p->last_launches[i];
+    return ZMLS_OK;
+}
+
 int zmls_plan_force_pseudo_channels(zmls_plan *p, int mode)
 {
     if (!p || mode < -1 || mode > 1) { set_error("pseudo-channel layout: mode must be -1 (auto), 0 (off) or 1 (on)"); return ZMLS_E_ARG; }
@@ -435,6 +442,17 @@ int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
 } // extern "C"
 
 namespace zmls {
+// does a batch of n_ch channels take the pseudo-channel layout on this plan (forced, or the measured rule pc_pays), and how
+// large is one of its slabs (one channel: 2^(N-PCB) rows of 128 bytes plus the padding rows)
+bool pc_applies(const zmls_plan *p, int64_t n_ch)
+{
+    return p->pc_npass > 0 && (p->force_pc > 0 || (p->force_pc < 0 && p->force_cfg < 0 && pc_pays(p->N, n_ch)));
+}
+size_t pc_slab_bytes(const zmls_plan *p)
+{
+    return p->pc_npass ? (size_t)work_rows_total(p->N - pc_bits_of(p->dtype)) * (kVecBytes << kCfg[CFG_MID].lu) : 0;
+}
+
 // plans of orders 31 and 32, and of taps that are not maximum-length, hold the bit sequence only
 int sequence_only(const zmls_plan *p)
 {
@@ -476,7 +494,13 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
                         ((uintptr_t)d_x % kVecBytes) == 0 && n_ch % E == 0;
     const bool vec_out = out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 &&
                          ((uintptr_t)d_h % kVecBytes) == 0 && n_ch % E == 0;
-    auto launch = (p->dtype == ZMLS_F64) ? launch_pass_f64 : launch_pass_f32;
+    auto launch_raw = (p->dtype == ZMLS_F64) ? launch_pass_f64 : launch_pass_f32;
+    // (kernel launches of this call by kind - first / middle / last pass - for the profile summaries: zmls_plan_last_launches)
+    p->last_launches[0] = p->last_launches[1] = p->last_launches[2] = 0;
+    auto launch = [&](int cfg_, int K_, int inm_, int outm_, const PassArgs &a_, hipStream_t s_) {
+        ++p->last_launches[inm_ != IN_WORK ? 0 : outm_ == OUT_WORK ? 1 : 2];
+        return launch_raw(cfg_, K_, inm_, outm_, a_, s_);
+    };
     // wide vector-aligned channel blocks stream through the mid tile (128-byte row segments, two
     // register-resident workgroups per CU); everything else through the small one
     // (measured on the N=20, 512-channel, 16-period batch: small 19.3 ms, big 15.9 ms, mid 14.9 ms per step).
@@ -507,9 +531,8 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
     // one such slab leaves the ordinary tiles to try.
     const int PCB = pc_bits_of(p->dtype);
     const int N_eff_pc = p->N - PCB;
-    const size_t pc_slab = p->pc_npass ? (size_t)work_rows_total(N_eff_pc) * (kVecBytes << kCfg[CFG_MID].lu) : 0;
-    const bool pc = p->pc_npass > 0 && (p->force_pc > 0 || (p->force_pc < 0 && p->force_cfg < 0 && pc_pays(p->N, n_ch))) &&
-                    (p->pc_npass == 1 || own_work || work_bytes >= pc_slab);
+    const size_t pc_slab = pc_slab_bytes(p);
+    const bool pc = pc_applies(p, n_ch) && (p->pc_npass == 1 || own_work || work_bytes >= pc_slab);
     if (pc) cfg = CFG_MID;
     const TileCfg tc = kCfg[cfg];
     const int N_eff = pc ? N_eff_pc : p->N;                         // transform bits the passes see
@@ -766,7 +789,7 @@ int impulse_device_core(zmls_plan *p, const void *d_x, int in_dtype, int64_t per
     const bool vec_in = in_dtype == p->dtype && ch_stride == 1 && (row_stride * (int64_t)ts) % kVecBytes == 0 &&
                         ((uintptr_t)d_x % kVecBytes) == 0 && n_ch % E == 0;
     const bool vec_out = out_ch_stride == 1 && (out_row_stride * (int64_t)ts) % kVecBytes == 0 && ((uintptr_t)d_h % kVecBytes) == 0 && n_ch % E == 0;
-    if (p->pc_npass > 0 && !gather_pass_only && (p->force_pc > 0 || (p->force_pc < 0 && p->force_cfg < 0 && pc_pays(p->N, n_ch)))) {
+    if (pc_applies(p, n_ch) && !gather_pass_only) {
         // Few channels - the reference's own call is one - take the pseudo-channel layout (run_passes), which reads and writes
         // any strides and sample types element by element: no layout adapters. Its 8-byte gathers want ONE period to gather
         // from, so with staging the periods are added up first, in time order and period order (coalesced; the same sums the

@@ -33,6 +33,7 @@
 // the chain z_1 = E_0, z_{r+1} = A^L z_r + E_r gives Z, and the filter then runs over ONE period of sums from the
 // initial state Z. Exact (every step is the same linear map, regrouped), the capture is read once and nothing of its
 // size is written: 19 instead of 54 ms for N=20, 512 channels x 17 periods.
+#include <algorithm>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -46,6 +47,7 @@ constexpr int kIirLevels = 17;     // P[d] = A^(32 * 2^d), d = 0..16: runs (d < 
 constexpr int kIirGroup = 256;     // chunks per group of the second-level scan
 constexpr int kIirSerialChunks = 16;   // up to here one thread per channel walks the chunks
 constexpr int kIirPitch = kIirSub + 1;
+constexpr size_t kIirSegmentBytes = 0;   // signal per segment of the time axis (launch_iir_s); 0 = one segment: segments of 64-192 MiB measured 14-28 % SLOWER (profiles/r03_iir_segments.txt)
 
 struct IirDev {
     double b[kIirMaxS + 1], a[kIirMaxS + 1];       // normalised: a[0] = 1
@@ -93,7 +95,8 @@ __device__ __forceinline__ double df2t_step(const IirDev *__restrict__ f, double
 template <int S, int CC, bool FINAL>
 __global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict__ f, const void *__restrict__ x, int in_dtype, int64_t n_rows,
                                                         int64_t n_ch, int64_t rs, int64_t cs, uint32_t n_cgrp, double *__restrict__ zc,
-                                                        const double *__restrict__ sin, double *__restrict__ y, int64_t ors, int64_t ocs)
+                                                        const double *__restrict__ sin, double *__restrict__ y, int64_t ors, int64_t ocs,
+                                                        int keep /* first sweep of a segment: the second sweep wants these lines in the Infinity Cache */)
 {
     constexpr int NB = 256 / CC;
     constexpr int LOGNB = (CC == 1) ? 8 : 4;
@@ -116,7 +119,8 @@ __global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int e = tid + i * 256, tt = e / CC, cc = e % CC;
-            r[i] = __builtin_nontemporal_load((const double *)x + (t0 + tt) * rs + (c0 + cc) * cs);     // each sweep reads the signal once
+            const double *q = (const double *)x + (t0 + tt) * rs + (c0 + cc) * cs;
+            r[i] = keep ? *q : __builtin_nontemporal_load(q);      // streaming, unless the other sweep of this segment comes right behind
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -294,45 +298,100 @@ __global__ void __launch_bounds__(256) iir_group_fix_kernel(const IirDev *__rest
     for (int k = 0; k < S; ++k) sin[idx * S + k] += w[k];
 }
 
+// the filter state after the last chunk of a segment = the start state of the next segment's first chunk:
+// A^chunk x (start state of the last chunk) + its zero-state end state. One thread per channel.
+template <int S>
+__global__ void __launch_bounds__(64) iir_carry_kernel(const IirDev *__restrict__ f, int level, int64_t n_chunks, int64_t n_ch,
+                                                       const double *__restrict__ zc, const double *__restrict__ sin, double *__restrict__ carry)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ch) return;
+    double s[S], e[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        s[k] = sin[((n_chunks - 1) * n_ch + c) * S + k];
+        e[k] = zc[((n_chunks - 1) * n_ch + c) * S + k];
+    }
+    matvec_acc<S>(f->P[level], s, e);
+#pragma unroll
+    for (int k = 0; k < S; ++k) carry[c * S + k] = e[k];
+}
+
 template <int S, int CC>
 int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs, double *d_zc, double *d_sin,
-                 double *d_zg, double *d_sg, double *d_y, int64_t ors, int64_t ocs, const double *d_zi, hipStream_t st)
+                 double *d_zg, double *d_sg, double *d_y, int64_t ors, int64_t ocs, const double *d_zi, double *d_carry, size_t segment_bytes,
+                 hipStream_t st)
 {
     constexpr int NB = 256 / CC, TT = NB * kIirSub, LOGNB = (CC == 1) ? 8 : 4;
-    const uint64_t n_cgrp = (uint64_t)((n_ch + CC - 1) / CC), n_chunks = (uint64_t)((n_rows + TT - 1) / TT);
-    const uint64_t blocks = n_cgrp * n_chunks;
-    if (blocks == 0 || blocks > 0x7FFFFFFFull) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
-    hipLaunchKernelGGL((iir_chunk_kernel<S, CC, false>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, n_rows, n_ch, rs, cs,
-                       (uint32_t)n_cgrp, d_zc, (const double *)nullptr, (double *)nullptr, ors, ocs);
-    if (n_chunks <= (uint64_t)kIirSerialChunks) {
-        hipLaunchKernelGGL(iir_combine_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
-                           (const double *)d_zc, d_sin, d_zi);
-    } else {
-        const uint64_t n_groups = (n_chunks + kIirGroup - 1) / kIirGroup;
-        if (n_groups * (uint64_t)n_ch > 0x7FFFFFFFull) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
-        hipLaunchKernelGGL(iir_group_scan_kernel<S>, dim3((uint32_t)(n_groups * n_ch)), dim3(kIirGroup), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
-                           (const double *)d_zc, d_sin, d_zg);
-        if (n_groups > 1 || d_zi) {
-            hipLaunchKernelGGL(iir_combine_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB + 8, (int64_t)n_groups, n_ch,
-                               (const double *)d_zg, d_sg, d_zi);
-            const int first_group = d_zi ? 0 : 1;
-            const uint64_t rest = (n_chunks - (uint64_t)first_group * kIirGroup) * (uint64_t)n_ch;
-            hipLaunchKernelGGL(iir_group_fix_kernel<S>, dim3((uint32_t)((rest + 255) / 256)), dim3(256), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
-                               (const double *)d_sg, d_sin, first_group);
-        }
+    const uint64_t n_cgrp = (uint64_t)((n_ch + CC - 1) / CC);
+    if (n_cgrp * (uint64_t)((n_rows + TT - 1) / TT) == 0 || n_cgrp * (uint64_t)((n_rows + TT - 1) / TT) > 0x7FFFFFFFull) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
+    // Segments of the time axis (round 3, a tuning option that is OFF by default): the signal is swept twice, and a segment
+    // small enough to stay in the 256 MiB Infinity Cache between its two sweeps could be read from HBM once. Whole chunks per
+    // segment, all channels; the state after a segment's last chunk (iir_carry_kernel) is the next segment's initial state.
+    // Measured (profiles/r03_iir_segments.txt, (2L, 512) frames x channels): 4.5 ms in one segment, 5.75 ms in segments of
+    // 64-128 MiB, 5.1 ms at 192 MiB, with streaming or cached first-sweep loads alike: the cache does not hand the second
+    // sweep its lines faster than HBM streams them, and the segments' launch ramps cost more than is saved.
+    int64_t seg_rows = n_rows;
+    if (segment_bytes && d_carry) {
+        const int64_t per_row = n_ch * 8;
+        seg_rows = std::max<int64_t>(1, (int64_t)(segment_bytes / (size_t)per_row) / TT) * TT;
+        // the grid of a segment should still fill the GPU a few times over
+        const int64_t min_chunks = (int64_t)((2048 + n_cgrp - 1) / n_cgrp);
+        if (seg_rows < min_chunks * TT) seg_rows = min_chunks * TT;
     }
-    hipLaunchKernelGGL((iir_chunk_kernel<S, CC, true>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, n_rows, n_ch, rs, cs,
-                       (uint32_t)n_cgrp, (double *)nullptr, (const double *)d_sin, d_y, ors, ocs);
+    const size_t is = dtype_size(in_dtype);
+    // ZMLS_IIR_KEEP=0/1 (tuning): the first sweep's loads streaming / cached, whatever the segment count
+    static const int keep_env = [] { const char *v = getenv("ZMLS_IIR_KEEP"); return (v && *v) ? atoi(v) : -1; }();
+    const int keep_first = keep_env >= 0 ? keep_env : (seg_rows < n_rows ? 1 : 0);
+    for (int64_t r0 = 0; r0 < n_rows; r0 += seg_rows) {
+        const int64_t rows = std::min<int64_t>(seg_rows, n_rows - r0);
+        const void *x_seg = (const char *)d_x + (size_t)(r0 * rs) * is;
+        double *y_seg = d_y + r0 * ors;
+        const double *zi_seg = r0 == 0 ? d_zi : d_carry;
+        const bool more = r0 + rows < n_rows;
+        const uint64_t n_chunks = (uint64_t)((rows + TT - 1) / TT);
+        const uint64_t blocks = n_cgrp * n_chunks;
+        hipLaunchKernelGGL((iir_chunk_kernel<S, CC, false>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, x_seg, in_dtype, rows, n_ch, rs, cs,
+                           (uint32_t)n_cgrp, d_zc, (const double *)nullptr, (double *)nullptr, ors, ocs, keep_first);
+        if (n_chunks <= (uint64_t)kIirSerialChunks) {
+            hipLaunchKernelGGL(iir_combine_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
+                               (const double *)d_zc, d_sin, zi_seg);
+        } else {
+            const uint64_t n_groups = (n_chunks + kIirGroup - 1) / kIirGroup;
+            if (n_groups * (uint64_t)n_ch > 0x7FFFFFFFull) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
+            hipLaunchKernelGGL(iir_group_scan_kernel<S>, dim3((uint32_t)(n_groups * n_ch)), dim3(kIirGroup), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
+                               (const double *)d_zc, d_sin, d_zg);
+            if (n_groups > 1 || zi_seg) {
+                hipLaunchKernelGGL(iir_combine_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB + 8, (int64_t)n_groups, n_ch,
+                                   (const double *)d_zg, d_sg, zi_seg);
+                const int first_group = zi_seg ? 0 : 1;
+                const uint64_t rest = (n_chunks - (uint64_t)first_group * kIirGroup) * (uint64_t)n_ch;
+                hipLaunchKernelGGL(iir_group_fix_kernel<S>, dim3((uint32_t)((rest + 255) / 256)), dim3(256), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
+                                   (const double *)d_sg, d_sin, first_group);
+            }
+        }
+        // (before the second sweep: in-place filtering overwrites nothing the carry needs, but the next segment's
+        // combine must not start before this one's start states have been read - stream order takes care of both)
+        if (more)
+            hipLaunchKernelGGL(iir_carry_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
+                               (const double *)d_zc, (const double *)d_sin, d_carry);
+        hipLaunchKernelGGL((iir_chunk_kernel<S, CC, true>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, x_seg, in_dtype, rows, n_ch, rs, cs,
+                           (uint32_t)n_cgrp, (double *)nullptr, (const double *)d_sin, y_seg, ors, ocs, 0);
+    }
     ZHIP(hipGetLastError());
     return ZMLS_OK;
 }
 
 template <int S>
 int launch_iir_cc(bool time_contiguous, const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs,
-                  double *d_zc, double *d_sin, double *d_zg, double *d_sg, double *d_y, int64_t ors, int64_t ocs, const double *d_zi, hipStream_t st)
+                  double *d_zc, double *d_sin, double *d_zg, double *d_sg, double *d_y, int64_t ors, int64_t ocs, const double *d_zi, double *d_carry,
+                  size_t segment_bytes, hipStream_t st)
 {
-    if (time_contiguous) return launch_iir_s<S, 1>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, d_zi, st);
-    return launch_iir_s<S, 16>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, d_zi, st);
+    // stacked single-channel signals (time-contiguous, several channels) are not cut: a segment of all channels is no contiguous
+    // piece of memory there and the channels are far apart anyway
+    if (time_contiguous) return launch_iir_s<S, 1>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, d_zi, d_carry,
+                                                   n_ch == 1 ? segment_bytes : 0, st);
+    return launch_iir_s<S, 16>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, d_zi, d_carry, segment_bytes, st);
 }
 
 // ---- the fused path: one sweep over the capture (period sums + chunk end states), then two small kernels
@@ -575,6 +634,9 @@ struct zmls_iir {
     double *d_zg, *d_sg;       // the same of every group of 256 chunks (1/256 of the above)
     size_t scratch_elems;      // of d_zc, d_sin each
     size_t group_elems;        // of d_zg, d_sg each: not monotonic in scratch_elems (few long channels against many short ones)
+    double *d_carry;           // filter state handed from one segment of the time axis to the next: n_ch x S
+    size_t carry_elems;
+    size_t segment_bytes;      // signal bytes per segment (0: one segment)
     // the fused de-emphasis + impulse response path (zmls_iir_reserve_fused)
     long double A[zmls::kIirMaxS * zmls::kIirMaxS];   // state matrix, S x S (host)
     double *d_e, *d_E, *d_zi, *d_sum, *d_phi;          // chunk end states of every period, period end states, sum of start states, period sums, A^L
@@ -640,7 +702,7 @@ int zmls::filtered_period_sums(zmls_plan *p, zmls_iir *f, const void *d_x, int i
     const int64_t srs = tc ? 1 : n_ch, scs = tc ? L : 1;
 #define ZPER(SS) case SS: rc = tc ? launch_period_s<SS, 1>(f->d_f, d_x, in_dtype, L, R, n_ch, row_stride, ch_stride, f->d_e, f->d_E, f->d_phi, f->d_zi, f->d_sum, srs, scs, st) \
                                   : launch_period_s<SS, 16>(f->d_f, d_x, in_dtype, L, R, n_ch, row_stride, ch_stride, f->d_e, f->d_E, f->d_phi, f->d_zi, f->d_sum, srs, scs, st); break;
-#define ZFIL(SS) case SS: rc = launch_iir_cc<SS>(tc, f->d_f, f->d_sum, ZMLS_F64, L, n_ch, srs, scs, f->d_zc, f->d_sin, f->d_zg, f->d_sg, f->d_sum, srs, scs, f->d_zi, st); break;
+#define ZFIL(SS) case SS: rc = launch_iir_cc<SS>(tc, f->d_f, f->d_sum, ZMLS_F64, L, n_ch, srs, scs, f->d_zc, f->d_sin, f->d_zg, f->d_sg, f->d_sum, srs, scs, f->d_zi, (size_t)n_ch * (size_t)f->S <= f->carry_elems ? f->d_carry : nullptr, f->segment_bytes, st); break;
     switch (f->S) {
         ZPER(1) ZPER(2) ZPER(3) ZPER(4) ZPER(5) ZPER(6) ZPER(7) ZPER(8)
     default: set_error("no filter kernel for order %d", f->S); return ZMLS_E_UNSUPPORTED;
@@ -694,6 +756,7 @@ int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, in
     if (!f) { set_error("out of host memory"); return ZMLS_E_ARG; }
     f->device = device;
     f->S = S;
+    f->segment_bytes = kIirSegmentBytes;
     memcpy(f->A, A_keep, sizeof A_keep);
     hipError_t e = hipMalloc((void **)&f->d_f, sizeof(IirDev));
     if (e == hipSuccess) e = hipMemcpy(f->d_f, &h, sizeof h, hipMemcpyHostToDevice);
@@ -717,6 +780,7 @@ int zmls_iir_destroy(zmls_iir *f)
         if (f->d_sin) (void)hipFree(f->d_sin);
         if (f->d_zg) (void)hipFree(f->d_zg);
         if (f->d_sg) (void)hipFree(f->d_sg);
+        if (f->d_carry) (void)hipFree(f->d_carry);
         double *fused[5] = {f->d_e, f->d_E, f->d_zi, f->d_sum, f->d_phi};
         for (double *q : fused)
             if (q) (void)hipFree(q);
@@ -742,6 +806,12 @@ int zmls_iir_reserve(zmls_iir *f, int64_t n_rows, int64_t n_ch)
         ZHIP(hipMalloc((void **)&f->d_sin, need * 8));
         f->scratch_elems = need;
     }
+    if ((size_t)n_ch * (size_t)f->S > f->carry_elems) {
+        if (f->d_carry) { ZHIP(hipFree(f->d_carry)); f->d_carry = nullptr; }
+        f->carry_elems = 0;
+        ZHIP(hipMalloc((void **)&f->d_carry, (size_t)n_ch * (size_t)f->S * 8));
+        f->carry_elems = (size_t)n_ch * (size_t)f->S;
+    }
     if (need_g > f->group_elems) {
         if (f->d_zg) { ZHIP(hipFree(f->d_zg)); f->d_zg = nullptr; }
         if (f->d_sg) { ZHIP(hipFree(f->d_sg)); f->d_sg = nullptr; }
@@ -750,6 +820,13 @@ int zmls_iir_reserve(zmls_iir *f, int64_t n_rows, int64_t n_ch)
         ZHIP(hipMalloc((void **)&f->d_sg, need_g * 8));
         f->group_elems = need_g;
     }
+    return ZMLS_OK;
+}
+
+int zmls_iir_set_segment(zmls_iir *f, size_t bytes)
+{
+    if (!f) { set_error("null argument"); return ZMLS_E_ARG; }
+    f->segment_bytes = bytes == (size_t)-1 ? kIirSegmentBytes : bytes;
     return ZMLS_OK;
 }
 
@@ -766,7 +843,7 @@ int zmls_iir_device(zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, 
     rc = iir_scratch_check(f, n_rows, n_ch, tt);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-#define ZIIR(SS) case SS: return launch_iir_cc<SS>(tc, f->d_f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, f->d_zc, f->d_sin, f->d_zg, f->d_sg, d_y, out_row_stride, out_ch_stride, nullptr, st);
+#define ZIIR(SS) case SS: return launch_iir_cc<SS>(tc, f->d_f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, f->d_zc, f->d_sin, f->d_zg, f->d_sg, d_y, out_row_stride, out_ch_stride, nullptr, (size_t)n_ch * (size_t)f->S <= f->carry_elems ? f->d_carry : nullptr, f->segment_bytes, st);
     switch (f->S) {
         ZIIR(1) ZIIR(2) ZIIR(3) ZIIR(4) ZIIR(5) ZIIR(6) ZIIR(7) ZIIR(8)
     default: break;

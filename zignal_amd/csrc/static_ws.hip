@@ -13,6 +13,7 @@
 // has to start at zero: the first pass writes every row of every slab of its chunk (rows of channels past
 // the end of the batch are written as zeros by the kernel) before a later pass reads them, and the padding
 // rows between them are never read. Calls that overlap on one GPU (two streams, two threads) race on it.
+#include <atomic>
 #include <mutex>
 #include "zmls_internal.h"
 
@@ -28,7 +29,7 @@ static_assert(work_rows_total(ZMLS_STATIC_MAX_ORDER) * (kVecBytes << kCfg[CFG_SM
 
 constexpr int kMaxDevices = 64;
 std::mutex g_mu;
-void *g_ptr[kMaxDevices];        // address of `scratch` on device d, once resolved
+std::atomic<void *> g_ptr[kMaxDevices];        // address of `scratch` on device d, once resolved (read without the lock)
 
 } // namespace
 
@@ -36,8 +37,14 @@ void *g_ptr[kMaxDevices];        // address of `scratch` on device d, once resol
 int static_workspace(int device, void **ptr, size_t *bytes)
 {
     if (device < 0 || device >= kMaxDevices) { set_error("device %d out of range for the static workspace", device); return ZMLS_E_ARG; }
+    void *known = g_ptr[device].load(std::memory_order_acquire);
+    if (known) {                                    // the launch path: resolved by zmls_plan_create, no lock taken
+        *ptr = known;
+        if (bytes) *bytes = kStaticBytes;
+        return ZMLS_OK;
+    }
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_ptr[device]) {
+    if (!g_ptr[device].load(std::memory_order_relaxed)) {
         int cur = -1;
         ZHIP(hipGetDevice(&cur));
         if (cur != device) { set_error("static workspace of device %d asked for while device %d is current", device, cur); return ZMLS_E_ARG; }
@@ -45,9 +52,9 @@ int static_workspace(int device, void **ptr, size_t *bytes)
         hipError_t e = hipGetSymbolAddress((void **)&q, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return hip_fail(e, "hipGetSymbolAddress(scratch)");
         if (!q) { set_error("hipGetSymbolAddress returned no address for the static workspace"); return ZMLS_E_HIP; }
-        g_ptr[device] = q;
+        g_ptr[device].store(q, std::memory_order_release);
     }
-    *ptr = g_ptr[device];
+    *ptr = g_ptr[device].load(std::memory_order_relaxed);
     if (bytes) *bytes = kStaticBytes;
     return ZMLS_OK;
 }
@@ -67,9 +74,11 @@ extern "C" int zmls_impulse_device_static(zmls_plan *p, const void *d_x, int in_
     size_t ws_bytes = 0;
     rc = static_workspace(p->device, &ws, &ws_bytes);       // resolved by zmls_plan_create; here it is a table look-up
     if (rc) return rc;
-    // the limit, stated before anything is launched: one 64-byte-row slab (the narrowest tile) of the order must fit
+    // the limit, stated before anything is launched: one 64-byte-row slab (the narrowest tile) of the order must fit - or,
+    // for the few channels that take the pseudo-channel layout, one of its sixteen times smaller slabs (one channel up to N = 24)
     const size_t narrowest = (size_t)work_rows_total(p->N) * (kVecBytes << kCfg[CFG_SMALL].lu);
-    if (p->npass > 1 && narrowest > ws_bytes) {
+    const bool pc_fits = n_ch >= 1 && pc_applies(p, n_ch) && (p->pc_npass == 1 || pc_slab_bytes(p) <= ws_bytes);
+    if (p->npass > 1 && narrowest > ws_bytes && !pc_fits) {
         set_error("order %d is beyond zmls_impulse_device_static: one channel slab of its intermediate is %zu bytes, the static "
                   "workspace holds %zu (orders up to %d); use zmls_plan_reserve + zmls_impulse_device",
                   p->N, narrowest, ws_bytes, ZMLS_STATIC_MAX_ORDER);

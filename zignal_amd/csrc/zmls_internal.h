@@ -161,6 +161,8 @@ struct DeviceScope {
     ::zmls::DeviceScope ZCAT(zscope_, __LINE__)(dev);         \
     if (ZCAT(zscope_, __LINE__).rc) return ZCAT(zscope_, __LINE__).rc
 hipError_t settled_malloc(void **ptr, size_t bytes);
+bool pc_applies(const zmls_plan *p, int64_t n_ch);       // api.hip: the pseudo-channel layout serves a batch of n_ch channels
+size_t pc_slab_bytes(const zmls_plan *p);                // ... in slabs of this size, one per channel
 // pageable host memory <-> device memory, large copies in chunks through pinned bounce buffers on several streams (hostcopy.hip)
 int host_copy(int device, void *d_ptr, void *h_ptr, size_t bytes, bool to_device);
 
@@ -205,6 +207,7 @@ struct zmls_plan {
     int tall_bits[4];
     int pc_npass;                 // pass split of the N - 4 (f64) / N - 5 (f32) row bits of the pseudo-channel layout, 0 when the order is too small for it
     int pc_bits[4];
+    int last_launches[3];         // pass-kernel launches of the most recent run_passes call: first (gather) pass, middle passes, last (scatter) pass
     int force_pc;                 // -1: few-channel batches take the pseudo-channel layout, 0: never, 1: whenever it applies (tests, tuning)
     uint32_t s0;                  // Fibonacci state at n = 0 (first N sequence bits)
     int maximal;                  // the register's period is 2^N - 1 (else: the sequence is generated, the transform refused)

@@ -93,6 +93,12 @@ class Plan:
         """pseudo-channel layout of few-channel batches (tests / tuning): -1 the library decides, 0 never, 1 whenever the order allows"""
         L.check(L.lib().zmls_plan_force_pseudo_channels(self._h, int(mode)))
 
+    def last_launches(self):
+        """pass-kernel launches of the most recent impulse call: [first (gather) pass, middle passes, last (scatter) pass]"""
+        out = (ctypes.c_int32 * 3)()
+        L.check(L.lib().zmls_plan_last_launches(self._h, out))
+        return list(out)
+
     def set_resident(self, mode=-1, nbytes=0, flags=0):
         """cache-resident schedule (tests / tuning): -1 the library decides, 0 off, 1 on; chunk bytes (0 = built-in); flags"""
         L.check(L.lib().zmls_plan_set_resident(self._h, int(mode), int(nbytes), int(flags)))
@@ -302,6 +308,10 @@ class IirFilter:
 
     def reserve(self, n_rows, n_ch):
         L.check(L.lib().zmls_iir_reserve(self._h, int(n_rows), int(n_ch)))
+
+    def set_segment(self, nbytes=None):
+        """bytes of signal per segment of the time axis (tests / tuning): None the library's own size, 0 one segment"""
+        L.check(L.lib().zmls_iir_set_segment(self._h, ctypes.c_size_t(-1).value if nbytes is None else int(nbytes)))
 
     def reserve_fused(self, plan, n_rows, n_ch):
         """scratch for Plan.impulse_filtered_device on captures of n_rows frames x n_ch channels (zmls_iir_reserve_fused)"""
