@@ -152,6 +152,83 @@ __global__ void __launch_bounds__(256) spectrum_db_pairs_kernel(const double2 *_
     }
 }
 
+// ---- the same three steps of the packed mode for frame-major responses (channels adjacent in memory, the layout the
+// impulse entry points write): adjacent lanes walk CHANNELS on the response side and FRAMES / BINS on the transform side, so a
+// 64 x 64 tile crosses LDS in between and both sides move whole 512-byte rows. (One element per lane with frames on the lanes
+// read 8 bytes out of every 512: the three kernels took 36 % of the call, profiles/r03_spectrum_kernel_stats.csv.)
+constexpr int kSpT = 64;            // frames (bins) and channels per tile
+
+__global__ void __launch_bounds__(256) spectrum_peak_rows_kernel(const double *__restrict__ h, int64_t n, int64_t n_ch, int64_t row_stride,
+                                                                 const double *__restrict__ window, int64_t rows_per_block,
+                                                                 unsigned long long *__restrict__ peak)
+{
+    __shared__ double red[256];
+    const int lane_c = threadIdx.x & (kSpT - 1), rg = threadIdx.x >> 6;           // channel within the tile, row group 0..3
+    const int64_t c = (int64_t)blockIdx.y * kSpT + lane_c;
+    const int64_t t_begin = (int64_t)blockIdx.x * rows_per_block, t_end = t_begin + rows_per_block < n ? t_begin + rows_per_block : n;
+    double m = 0.0;
+    if (c < n_ch) {
+        for (int64_t t = t_begin + rg; t < t_end; t += 4) {
+            const double v = fabs(h[t * row_stride + c] * (window ? window[t] : 1.0));
+            if (v > m && v <= 1.7976931348623157e308) m = v;
+        }
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    if (rg == 0 && c < n_ch) {
+        m = fmax(fmax(red[lane_c], red[64 + lane_c]), fmax(red[128 + lane_c], red[192 + lane_c]));
+        if (m > 0.0) atomicMax(peak + c, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+__global__ void __launch_bounds__(256) spectrum_prepare_pairs_rows_kernel(const double *__restrict__ h, int64_t n, int64_t n_ch, int64_t row_stride,
+                                                                          const double *__restrict__ window, int64_t n_pairs,
+                                                                          const unsigned long long *__restrict__ peak, double2 *__restrict__ stage)
+{
+    __shared__ double tile[kSpT][kSpT + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * kSpT, c0 = (int64_t)blockIdx.y * kSpT;
+    for (int r = wv; r < kSpT; r += 4) {
+        const int64_t t = t0 + r, c = c0 + lane;
+        tile[r][lane] = (t < n && c < n_ch) ? h[t * row_stride + c] * (window ? window[t] : 1.0) : 0.0;
+    }
+    __syncthreads();
+    // pair pl of the tile, frame lane: 16 bytes per lane, 1 KiB per wave, contiguous in stage[p][t0 ...]
+    for (int pl = wv; pl < kSpT / 2; pl += 4) {
+        const int64_t p = c0 / 2 + pl, t = t0 + lane;
+        if (p < n_pairs && t < n) {
+            double2 v;
+            v.x = tile[lane][2 * pl];
+            v.y = ldexp(tile[lane][2 * pl + 1], pair_shift(peak, p, n_ch));
+            stage[p * n + t] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) spectrum_db_pairs_rows_kernel(const double2 *__restrict__ Y, int64_t F, int64_t n_bins, int64_t n_ch, int64_t n_pairs,
+                                                                     double scale, const unsigned long long *__restrict__ peak, double *__restrict__ mag)
+{
+    __shared__ double tile[kSpT][kSpT + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t k0 = (int64_t)blockIdx.x * kSpT, c0 = (int64_t)blockIdx.y * kSpT;
+    for (int pl = wv; pl < kSpT / 2; pl += 4) {
+        const int64_t p = c0 / 2 + pl, k = k0 + lane;
+        double m1 = 0.0, m2 = 0.0;
+        if (p < n_pairs && k < n_bins) {
+            const double2 a = Y[p * F + k], b = Y[p * F + (k ? F - k : 0)];
+            m1 = 0.5 * hypot(a.x + b.x, a.y - b.y);
+            m2 = ldexp(0.5 * hypot(a.x - b.x, a.y + b.y), -pair_shift(peak, p, n_ch));
+        }
+        tile[lane][2 * pl] = m1;
+        tile[lane][2 * pl + 1] = m2;
+    }
+    __syncthreads();
+    for (int r = wv; r < kSpT; r += 4) {
+        const int64_t k = k0 + r, c = c0 + lane;
+        if (k < n_bins && c < n_ch) mag[k * n_ch + c] = 20.0 * log10(tile[r][lane] * scale);
+    }
+}
+
 bool mersenne_prime_size(int64_t n)
 {
     return n == ((int64_t)1 << 13) - 1 || n == ((int64_t)1 << 17) - 1 || n == ((int64_t)1 << 19) - 1 || n == ((int64_t)1 << 31) - 1;
@@ -248,6 +325,23 @@ int zmls_spectrum_device(zmls_spectrum *s, const double *d_h, int64_t row_stride
     if (s->n_pairs) {
         // odd size: fftsize == n, nothing to pad
         ZHIP(hipMemsetAsync(s->d_peak, 0, (size_t)s->n_ch * 8, st));
+        const uint32_t c_tiles = (uint32_t)((s->n_ch + kSpT - 1) / kSpT);
+        if (ch_stride == 1 && c_tiles <= 65535u) {
+            // frame-major responses: whole rows of adjacent channels on the response side, whole runs of frames / bins on the other
+            const int64_t rows_per_block = std::max<int64_t>(kSpT, (s->n + 4095) / 4096);
+            hipLaunchKernelGGL(spectrum_peak_rows_kernel, dim3((uint32_t)((s->n + rows_per_block - 1) / rows_per_block), c_tiles), dim3(256), 0, st, d_h, s->n,
+                               s->n_ch, row_stride, d_window, rows_per_block, s->d_peak);
+            hipLaunchKernelGGL(spectrum_prepare_pairs_rows_kernel, dim3((uint32_t)((s->n + kSpT - 1) / kSpT), c_tiles), dim3(256), 0, st, d_h, s->n, s->n_ch,
+                               row_stride, d_window, s->n_pairs, s->d_peak, (double2 *)s->d_stage);
+            ZHIP(hipGetLastError());
+            hipfftResult rq = F->SetStream(s->plan, st);
+            if (rq == HIPFFT_SUCCESS) rq = F->ExecZ2Z(s->plan, (hipfftDoubleComplex *)s->d_stage, (hipfftDoubleComplex *)s->d_Y, HIPFFT_FORWARD);
+            if (rq != HIPFFT_SUCCESS) { set_error("hipfftExecZ2Z failed with %d", (int)rq); return ZMLS_E_HIP; }
+            hipLaunchKernelGGL(spectrum_db_pairs_rows_kernel, dim3((uint32_t)((s->n_bins + kSpT - 1) / kSpT), c_tiles), dim3(256), 0, st, s->d_Y, s->fftsize,
+                               s->n_bins, s->n_ch, s->n_pairs, normalise ? 1.0 / (double)s->fftsize : 1.0, s->d_peak, d_mag);
+            ZHIP(hipGetLastError());
+            return ZMLS_OK;
+        }
         hipLaunchKernelGGL(spectrum_peak_kernel, dim3(std::min<uint32_t>(grid(s->n), 1024u), (uint32_t)std::min<int64_t>(s->n_ch, 65535)), dim3(256), 0, st, d_h, s->n, s->n_ch,
                            row_stride, ch_stride, d_window, s->d_peak);
         hipLaunchKernelGGL(spectrum_prepare_pairs_kernel, dim3(grid(s->n * s->n_pairs)), dim3(256), 0, st, d_h, s->n, s->n_ch, row_stride, ch_stride,
