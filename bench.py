@@ -269,6 +269,17 @@ def per_kernel(pass_ms, Ravg, L, es, C):
     return out
 
 
+def schedule_name(launches, passes):
+    """which launch order ran (csrc/api.hip::run_passes), read off the launch counts of one step"""
+    first, middle, last = launches
+    if passes <= 1 or first + middle + last <= 1:
+        return "one pass (whole transform in one tile)"
+    if first > 1:
+        return ("cache-resident: %d chunks, each through %s back to back (intermediate kept in the Infinity Cache)"
+                % (first, "passes 1 and 2, then pass 3 over the whole batch" if middle else "both passes"))
+    return "streaming: one launch per pass over the whole batch"
+
+
 def timed_passes(plan, d_x, code, n_rows, C, rs, cs, d_h, ors, ocs, reps):
     pass_ms = np.zeros(plan.info()["passes"])
     for _ in range(reps):
@@ -322,6 +333,8 @@ def run_extra_config(spec, dev, cpu_seconds, keep):
     sync(dev)
     wall_ms = (time.perf_counter() - t0) / steps * 1e3
     ms = tm.elapsed_ms() / steps
+    step()
+    launches = plan.last_launches()
     pass_ms = timed_passes(plan, d_x, code, n_rows, C, C, 1, d_h, C, 1, 2)
     alg = (Ravg + 1) * L * es * C
     out = {
@@ -331,7 +344,9 @@ def run_extra_config(spec, dev, cpu_seconds, keep):
         "ms_per_step": ms, "wall_ms_per_step": wall_ms, "value": C * Ravg * L / (ms * 1e-3) / 1e9, "unit": "Gsamples/s",
         "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_step": alg,
-                     "pass_ms": [float(v) for v in pass_ms], "per_kernel": per_kernel(pass_ms, Ravg, L, es, C)},
+                     "pass_ms": [float(v) for v in pass_ms], "per_kernel": per_kernel(pass_ms, Ravg, L, es, C),
+                     "launches_per_step": dict(zip(("first_pass", "middle_passes", "last_pass"), launches)),
+                     "schedule": schedule_name(launches, len(plan.info()["pass_bits"]))},
         "capture_placement": placement,
     }
     chans = sorted({0, C // 2, C - 1, C // 3})[:n_check] if C > 1 else [0]
@@ -638,6 +653,7 @@ def main():
             "per_kernel": per_kernel(pass_ms, Ravg, L, es, C),
             # the cache-resident schedule runs one step as several chunk launches of each pass kernel (csrc/api.hip::run_passes)
             "launches_per_step": dict(zip(("first_pass", "middle_passes", "last_pass"), plan.last_launches())),
+            "schedule": schedule_name(plan.last_launches(), len(pass_ms)),
         },
         "plan_build_s": plan_build_s,
         # the spread over the ranks (placement plateaus differ from GPU to GPU: DESIGN.md §3): wall time per step of every
