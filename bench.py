@@ -275,8 +275,10 @@ def schedule_name(launches, passes):
     if passes <= 1 or first + middle + last <= 1:
         return "one pass (whole transform in one tile)"
     if first > 1:
-        return ("cache-resident: %d chunks, each through %s back to back (intermediate kept in the Infinity Cache)"
-                % (first, "passes 1 and 2, then pass 3 over the whole batch" if middle else "both passes"))
+        if middle:
+            return ("cache-resident: %d chunks of top-bit ranges, each through passes 1 and 2 back to back (intermediate kept in the "
+                    "Infinity Cache), then pass 3 over the whole batch" % first)
+        return "cache-resident: %d chunks of channel slabs, each through both passes back to back (intermediate kept in the Infinity Cache)" % first
     return "streaming: one launch per pass over the whole batch"
 
 
