@@ -127,6 +127,7 @@ def test_one_channel_of_a_large_order_recovers_the_known_system(N, R):
     p = Plan(N, taps, device=0)
     L = p.L
     p.reserve(1, staging=True)
+    assert p.info()["workspace_bytes"] <= 1.01 * (1 << N) * 8           # one pseudo-channel slab: a sixteenth of a 128-byte-row one
     dx = DeviceBuffer(R * L * 8)
     dh = DeviceBuffer(L * 8)
     p.synth_device(dx.ptr, _lib.ZMLS_F64, R, 1, 1, 1, seed=99, sigma=1e-3)
@@ -138,6 +139,7 @@ def test_one_channel_of_a_large_order_recovers_the_known_system(N, R):
     exp[(d + np.arange(16)) % L] += g * (1.0 + 1.0 / L)
     assert np.max(np.abs(got - exp)) <= 1e-4         # the capture carries noise of sigma 1e-3, averaged by the correlation
     p.force_pseudo_channels(0)
+    p.reserve(1, staging=True)                       # the ordinary slabs are larger
     p.impulse_device(dx.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, dh.ptr, 1, 1)
     sync(0)
     assert rel_err(got, dh.download((L,), np.float64)) <= 1e-13

@@ -248,7 +248,10 @@ int zmls_plan_reserve(zmls_plan *p, int64_t n_ch)
     // wide one only when the batch fills at least one of its slabs or it is forced (a 256-byte slab of a 2^30-point
     // transform alone is 275 GB: single-channel plans of the largest orders must not be charged for it)
     size_t need = 0;
-    for (int c = 0; c < CFG_COUNT; ++c) {
+    // the few channels that take the pseudo-channel layout need one of its slabs each - a sixteenth of an ordinary one (one
+    // channel of N = 28: 2 GiB instead of 17)
+    if (pc_applies(p, n_ch)) need = p->pc_npass > 1 ? (size_t)n_ch * pc_slab_bytes(p) : 0;
+    for (int c = 0; c < CFG_COUNT && !pc_applies(p, n_ch); ++c) {
         const int cs = chans_per_slab(p, c);
         if (c != CFG_SMALL && n_ch < cs && p->force_cfg != c) continue;
         if (c == CFG_BIG && p->force_cfg != CFG_BIG) continue;         // the big tile is only ever used when forced
@@ -273,7 +276,7 @@ int zmls_plan_reserve_staging(zmls_plan *p, int64_t n_ch)
     const size_t ts = dtype_size(p->dtype);
     const int64_t E = (int64_t)(kVecBytes / ts);
     const size_t need = (size_t)p->L * (size_t)((n_ch + E - 1) / E * E) * ts;
-    rc = zmls_plan_reserve(p, (n_ch + E - 1) / E * E);
+    rc = zmls_plan_reserve(p, pc_applies(p, n_ch) ? n_ch : (n_ch + E - 1) / E * E);
     if (rc) return rc;
     if (need <= p->stage_bytes) return ZMLS_OK;
     for (int i = 0; i < 2; ++i) {
