@@ -5,8 +5,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zignal_amd.device import DeviceBuffer, sync
 
-for mib in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024):
-    n = mib << 20
+for kib in (4, 16, 64, 128, 256, 512, 1024, 2048, 3072, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576):
+    n = kib << 10
     a = np.random.default_rng(0).integers(0, 256, size=n, dtype=np.uint8)
     d = DeviceBuffer(n)
     d.upload(a); d.download((n,), np.uint8)
@@ -18,5 +18,5 @@ for mib in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024):
         import ctypes
         from zignal_amd import _lib
         t0 = time.perf_counter(); _lib.check(_lib.lib().zmls_dev_download(0, out.ctypes.data, d.ptr, n)); down.append(time.perf_counter() - t0)
-    print("%5d MiB: up %.3f ms = %.1f GB/s | down %.3f ms = %.1f GB/s" % (mib, min(up) * 1e3, n / min(up) / 1e9, min(down) * 1e3, n / min(down) / 1e9), flush=True)
+    print("%8d KiB: up %.3f ms = %.1f GB/s | down %.3f ms = %.1f GB/s" % (kib, min(up) * 1e3, n / min(up) / 1e9, min(down) * 1e3, n / min(down) / 1e9), flush=True)
     d.free()

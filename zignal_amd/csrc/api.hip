@@ -2,6 +2,8 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <stdio.h>
 #include <algorithm>
 #include <atomic>
 #include <vector>
@@ -365,7 +367,8 @@ int zmls_sequence_bits(zmls_plan *p, uint8_t *out, int64_t nbits)
     int rc = ZMLS_OK;
     const size_t nbytes = (size_t)((nbits + 7) / 8);
     if (!nbytes) return ZMLS_OK;
-    ZHIP(hipMemcpy(out, p->d_bits, nbytes, hipMemcpyDeviceToHost));
+    rc = host_copy(p->device, p->d_bits, out, nbytes, false);
+    if (rc) return rc;
     if (nbits & 7) out[nbytes - 1] &= (uint8_t)((1u << (nbits & 7)) - 1u);
     return ZMLS_OK;
 }
@@ -386,10 +389,7 @@ int zmls_sequence_bits_from(zmls_plan *p, uint64_t start, uint8_t *out, int64_t 
     ZHIP(hipMalloc((void **)&d, n_words * 4));
     rc = launch_lfsr_tables(p->N, p->G, s_at, p->d_jt, d, n_words, nullptr, nullptr, p->maximal, 0);
     const size_t nbytes = (size_t)((nbits + 7) / 8);
-    if (!rc) {
-        hipError_t e = hipMemcpy(out, d, nbytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(sequence bits)");
-    }
+    if (!rc) rc = host_copy(p->device, d, out, nbytes, false);
     (void)hipFree(d);
     if (!rc && (nbits & 7)) out[nbytes - 1] &= (uint8_t)((1u << (nbits & 7)) - 1u);
     return rc;
@@ -419,10 +419,7 @@ int zmls_sequence_f64(zmls_plan *p, double *out, int64_t repeats)
     double *d = nullptr;
     ZHIP(hipMalloc((void **)&d, (size_t)p->L * 8));
     rc = launch_sequence_expand(p->d_bits, p->L, d, ZMLS_F64, 1, 1, 0);
-    if (!rc) {
-        hipError_t e = hipMemcpy(out, d, (size_t)p->L * 8, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(sequence)");
-    }
+    if (!rc) rc = host_copy(p->device, d, out, (size_t)p->L * 8, false);
     (void)hipFree(d);
     if (rc) return rc;
     // np.tile, mls.py:164. The caller's array is usually fresh (numpy.empty: every page faults on first touch), so long
@@ -951,6 +948,11 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
     const size_t out_span = (size_t)((p->L - 1) * out_row_stride + (n_ch - 1) * out_ch_stride + 1) * ts;
     const bool out_dense = out_span == (size_t)p->L * (size_t)n_ch * ts;          // every byte of the span is ours
     const char *x_from = (const char *)x + (size_t)p->L * (size_t)row_stride * is;
+    // ZMLS_TRACE_HOST=1 (diagnostics): where the call's time goes, to stderr
+    static const bool trace = [] { const char *v = getenv("ZMLS_TRACE_HOST"); return v && *v == '1'; }();
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
+    const double t_begin = trace ? now() : 0.0;
+    double t_up = 0.0, t_launch = 0.0;
     void *d_x = nullptr, *d_h = nullptr;
     bool free_x = false, free_h = false;
     rc = host_call_buffer(p, 0, in_span, &d_x, &free_x);
@@ -967,9 +969,13 @@ int zmls_impulse_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
         // a strided view of a larger array: keep the bytes between the elements we own
         if (!rc && !out_dense) rc = host_copy(p->device, d_h, h, out_span, true);
     }
+    if (trace) t_up = now();
     if (!rc) rc = impulse_device_core(p, d_x, in_dtype, periods, 0, periods, n_ch, row_stride, dev_cs, d_h, out_row_stride, out_ch_stride,
                                       nullptr, nullptr, nullptr, 0);
+    if (trace) t_launch = now();
     if (!rc) rc = host_copy(p->device, d_h, h, out_span, false);                 // ordered after the kernels on the null stream
+    if (trace) fprintf(stderr, "zmls_impulse_host N=%d: reserve + upload of %zu bytes %.0f us, launches %.0f us, kernels + download of %zu bytes %.0f us\n",
+                       p->N, in_span, t_up - t_begin, t_launch - t_up, out_span, now() - t_launch);
     if (free_x && d_x) (void)hipFree(d_x);
     if (free_h && d_h) (void)hipFree(d_h);
     return rc;
@@ -1084,8 +1090,7 @@ int zmls_average_host(zmls_plan *p, const void *x, int in_dtype, int64_t n_rows,
     if (!rc) rc = host_copy(p->device, d_x, (void *)x, in_span, true);
     if (!rc) rc = launch_average(d_x, in_dtype, p->L, n_rows / p->L - 1, n_ch, row_stride, ch_stride, d_o, 0);
     if (!rc) {
-        e = hipMemcpy(out, d_o, out_bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = hip_fail(e, "average_host download");
+        rc = host_copy(p->device, d_o, out, out_bytes, false);
     }
     if (d_x) (void)hipFree(d_x);
     if (d_o) (void)hipFree(d_o);
@@ -1114,8 +1119,7 @@ int zmls_plan_export_table(zmls_plan *p, int which, uint32_t *out)
     if (int rc0 = sequence_only(p)) return rc0;
     ZDEVICE(p->device);
     int rc = ZMLS_OK;
-    ZHIP(hipMemcpy(out, which == 0 ? p->d_gather : p->d_scatter_nat, ((size_t)1 << p->N) * 4, hipMemcpyDeviceToHost));
-    return ZMLS_OK;
+    return host_copy(p->device, which == 0 ? p->d_gather : p->d_scatter_nat, out, ((size_t)1 << p->N) * 4, false);
 }
 
 // tuning only: replace the gather table (which = 0) by the caller's, e.g. a sorted one, to time the gather pass on
@@ -1249,10 +1253,7 @@ int zmls_dev_download_channel(int device, void *dst, const void *d_src, int dtyp
     void *d_tmp = nullptr;
     ZHIP(hipMalloc(&d_tmp, (size_t)n_rows * es));
     rc = launch_extract_channel(d_tmp, d_src, dtype, n_rows, row_stride, ch_stride, channel, 0);
-    if (!rc) {
-        hipError_t e = hipMemcpy(dst, d_tmp, (size_t)n_rows * es, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = hip_fail(e, "download_channel");
-    }
+    if (!rc) rc = host_copy(device, d_tmp, dst, (size_t)n_rows * es, false);
     (void)hipFree(d_tmp);
     return rc;
 }

@@ -8,20 +8,26 @@
 // first large copy, asleep on a condition variable in between, never started per call (per-call threads and per-call pinned
 // allocations are what sank round 2's probe, tools/pin_probe.hip) - move through pinned bounce buffers of their own, two per
 // thread, each on its own stream: while one chunk's DMA runs the thread copies the next into (or the previous out of) the other
-// buffer. The calling thread works as one of them. Small copies stay with hipMemcpy.
+// buffer. The calling thread works as one of them. Copies of 64 KiB ... 1 MiB go through the calling thread's own pinned buffers
+// alone (no helper is woken up); only below 64 KiB does hipMemcpy stay. Why not leave the middle to hipMemcpy: on this pool a
+// pageable copy of 64 KiB ... 1 MiB crawls at 2.5-2.8 GB/s (512 KiB: 0.19 ms against 0.03 here), and the same 2 MiB upload takes
+// anything between 74 and 720 us from one call to the next (ZMLS_TRACE_HOST=1 prints where a host call's time goes).
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <stdio.h>
+#include <time.h>
 #include "zmls_internal.h"
 
 namespace zmls {
 namespace {
 
 constexpr size_t kChunk = (size_t)4 << 20;          // bytes per bounce buffer (smaller copies are cut finer, Engine::run)
-constexpr size_t kEngineFrom = (size_t)4 << 20;     // copies from this size on go through the engine
+constexpr size_t kEngineFrom = (size_t)1 << 20;     // copies from this size on go through the engine (all threads)
+constexpr size_t kSmallFrom = (size_t)64 << 10;     // ... and from this size on through the calling thread's own pinned buffers,
 constexpr int kWorkers = 4;                         // the calling thread included
 
 struct Worker {
@@ -100,6 +106,21 @@ struct Engine {
         }
     }
 
+    // copies below the engine's threshold: the calling thread alone, through its own two pinned buffers and stream (no helper is
+    // woken up). One pageable hipMemcpy of 64 KiB ... 1 MiB takes 0.03-0.35 ms on this pool (2.5-2.8 GB/s); this takes the time
+    // of one host memcpy plus one DMA (512 KiB: 0.19 -> 0.03 ms, profiles/r03_hostcopy_rates.txt).
+    int run_small(void *d, void *h, size_t n, bool up)
+    {
+        std::lock_guard<std::mutex> one(call);
+        dev = (char *)d; host = (char *)h; bytes = n; to_device = up;
+        chunk = (size_t)512 << 10;                  // both buffers in flight from 1 MiB up: the host memcpy of one piece beside the DMA of the other
+        n_chunks = (n + chunk - 1) / chunk;
+        next = 0; err = 0;
+        work(0);
+        if (err.load()) { (void)hipGetLastError(); set_error("host copy of %zu bytes through the pinned buffers failed", n); return ZMLS_E_HIP; }
+        return ZMLS_OK;
+    }
+
     int run(void *d, void *h, size_t n, bool up)
     {
         std::lock_guard<std::mutex> one(call);
@@ -153,7 +174,22 @@ Engine *engine_for(int device)
 
 // dst/src: one of them device memory on `device` (current), the other pageable host memory. Ordered like hipMemcpy on the
 // null stream: everything enqueued before is complete before the first byte moves, and the copy is complete on return.
+static int host_copy_untraced(int device, void *d_ptr, void *h_ptr, size_t bytes, bool to_device);
+
 int host_copy(int device, void *d_ptr, void *h_ptr, size_t bytes, bool to_device)
+{
+    // ZMLS_TRACE_HOST=1 (diagnostics): every host copy with its time, to stderr
+    static const bool trace = [] { const char *v = getenv("ZMLS_TRACE_HOST"); return v && *v == '1'; }();
+    if (!trace) return host_copy_untraced(device, d_ptr, h_ptr, bytes, to_device);
+    timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    const int rc = host_copy_untraced(device, d_ptr, h_ptr, bytes, to_device);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    fprintf(stderr, "  host_copy %s %zu bytes: %.0f us\n", to_device ? "up" : "down", bytes, (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3);
+    return rc;
+}
+
+static int host_copy_untraced(int device, void *d_ptr, void *h_ptr, size_t bytes, bool to_device)
 {
     if (!bytes) return ZMLS_OK;
     // ZMLS_HOSTCOPY_MIN_BYTES: the size from which copies go through the engine (tuning; a huge value switches it off)
@@ -161,7 +197,19 @@ int host_copy(int device, void *d_ptr, void *h_ptr, size_t bytes, bool to_device
         const char *v = getenv("ZMLS_HOSTCOPY_MIN_BYTES");
         return (v && *v) ? (size_t)strtoull(v, nullptr, 10) : kEngineFrom;
     }();
-    Engine *e = bytes >= from ? engine_for(device) : nullptr;
+    // ZMLS_HOSTCOPY_SMALL_MIN_BYTES: from this size up to the engine's threshold the calling thread copies through its pinned buffer
+    static const size_t small_from = [] {
+        const char *v = getenv("ZMLS_HOSTCOPY_SMALL_MIN_BYTES");
+        return (v && *v) ? (size_t)strtoull(v, nullptr, 10) : kSmallFrom;
+    }();
+    // ZMLS_HOSTCOPY_SMALL_DIRS (tuning): 3 both directions (default), 1 uploads only, 2 downloads only, 0 neither
+    static const int dirs = [] { const char *v = getenv("ZMLS_HOSTCOPY_SMALL_DIRS"); return (v && *v) ? atoi(v) : 3; }();
+    auto small_dir = [&](bool up) { return (dirs & (up ? 1 : 2)) != 0; };
+    Engine *e = (bytes >= from || (bytes >= small_from && small_dir(to_device))) ? engine_for(device) : nullptr;
+    if (e && bytes < from) {
+        ZHIP(hipDeviceSynchronize());
+        return e->run_small(d_ptr, h_ptr, bytes, to_device);
+    }
     if (!e) {
         ZHIP(to_device ? hipMemcpy(d_ptr, h_ptr, bytes, hipMemcpyHostToDevice) : hipMemcpy(h_ptr, d_ptr, bytes, hipMemcpyDeviceToHost));
         return ZMLS_OK;
