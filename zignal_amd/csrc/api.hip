@@ -1129,8 +1129,7 @@ int zmls_plan_import_table(zmls_plan *p, int which, const uint32_t *in)
     if (!p || !in || which != 0) { set_error("bad import arguments"); return ZMLS_E_ARG; }
     if (int rc0 = sequence_only(p)) return rc0;
     ZDEVICE(p->device);
-    ZHIP(hipMemcpy(p->d_gather, in, ((size_t)1 << p->N) * 4, hipMemcpyHostToDevice));
-    return ZMLS_OK;
+    return host_copy(p->device, p->d_gather, (void *)in, ((size_t)1 << p->N) * 4, true);
 }
 
 // ---- thin HIP wrappers for ctypes callers ---------------------------------------------------

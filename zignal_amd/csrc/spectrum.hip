@@ -378,7 +378,7 @@ int zmls_spectrum_host(zmls_spectrum *s, const double *h, const double *window, 
     if (e == hipSuccess) e = hipMalloc((void **)&d_m, mb);
     if (e == hipSuccess && window) e = hipMalloc((void **)&d_w, (size_t)s->n * 8);
     if (e == hipSuccess && host_copy(s->device, d_h, (void *)h, hb, true) != ZMLS_OK) e = hipErrorUnknown;
-    if (e == hipSuccess && window) e = hipMemcpy(d_w, window, (size_t)s->n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && window && host_copy(s->device, d_w, (void *)window, (size_t)s->n * 8, true) != ZMLS_OK) e = hipErrorUnknown;
     if (e != hipSuccess) rc = hip_fail(e, "spectrum staging");
     if (!rc) rc = zmls_spectrum_device(s, d_h, s->n_ch, 1, d_w, normalise, d_m, nullptr);
     if (!rc) {
