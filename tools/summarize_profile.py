@@ -33,9 +33,17 @@ for name in ("fetch", "write", "sq", "tcc", "grbm", "wrreq", "rdreq", "sq2", "tc
     f = one(src + name + "/vm/*_counter_collection.csv")
     if not f:
         continue
+    # a kernel's launches inside the steps all have one grid size; the same kernel is also launched on other grids outside
+    # them (the placement search rates candidates with one full-size gather pass even where a step runs it chunk by chunk):
+    # only the launches of the most common grid size count
+    rows = [r for r in csv.DictReader(open(f)) if "fwht_pass_kernel" in r["Kernel_Name"]]
+    grids = collections.defaultdict(collections.Counter)
+    for r in rows:
+        grids[r["Kernel_Name"]][r["Grid_Size"]] += 1
+    modal = {k: c.most_common(1)[0][0] for k, c in grids.items()}
     acc = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
-        if "fwht_pass_kernel" in r["Kernel_Name"]:
+    for r in rows:
+        if r["Grid_Size"] == modal[r["Kernel_Name"]]:
             a = acc[(r["Kernel_Name"], r["Counter_Name"])]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
