@@ -207,7 +207,14 @@ static int host_copy_untraced(int device, void *d_ptr, void *h_ptr, size_t bytes
     auto small_dir = [&](bool up) { return (dirs & (up ? 1 : 2)) != 0; };
     Engine *e = (bytes >= from || (bytes >= small_from && small_dir(to_device))) ? engine_for(device) : nullptr;
     if (e && bytes < from) {
+        static const bool trace = [] { const char *v = getenv("ZMLS_TRACE_HOST"); return v && *v == '1'; }();
+        timespec a, b;
+        if (trace) clock_gettime(CLOCK_MONOTONIC, &a);
         ZHIP(hipDeviceSynchronize());
+        if (trace) {
+            clock_gettime(CLOCK_MONOTONIC, &b);
+            fprintf(stderr, "    (device synchronisation before it: %.0f us)\n", (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3);
+        }
         return e->run_small(d_ptr, h_ptr, bytes, to_device);
     }
     if (!e) {
