@@ -353,8 +353,8 @@ def run_extra_config(spec, dev, cpu_seconds, keep):
     }
     if key == "config1":
         # the reference's own call, numpy in and numpy out through zmls_impulse_host (upload, kernels, download); measured before
-        # this configuration's oracle leg (with the plan's host-call buffers allocated after it the same calls took 0.28 instead of
-        # 0.11 ms: where a buffer lands matters to the copy engines too)
+        # this configuration's checks and oracle leg (measured after them, the same 40 calls took 0.28 instead of 0.11 ms each in this
+        # process, copy by copy - ZMLS_TRACE_HOST=1 - and tools/config1_host_calls.py could not reproduce that outside bench.py: cause not found)
         x = np.ascontiguousarray(d_x.download((n_rows, 1), np.float64))
         plan.impulse_host(x)
         ts = []
