@@ -924,6 +924,7 @@ int zmls_iir_host(zmls_iir *f, const void *x, int in_dtype, int64_t n_rows, int6
     if (n_rows < 1 || n_ch < 1 || row_stride < 1 || ch_stride < 1) { set_error("bad shape/strides"); return ZMLS_E_ARG; }
     int rc = zmls_iir_reserve(f, n_rows, n_ch);
     if (rc) return rc;
+    ZDEVICE(f->device);                 // the staging buffers and the copies below belong to the filter's device
     const size_t in_span = (size_t)((n_rows - 1) * row_stride + (n_ch - 1) * ch_stride + 1) * is;
     const size_t out_bytes = (size_t)n_rows * n_ch * 8;
     void *d_x = nullptr;
