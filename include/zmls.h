@@ -260,8 +260,9 @@ int zmls_iir_host(zmls_iir *f, const void *x, int in_dtype, int64_t n_rows, int6
 
 /* ---- magnitude response: replaces Audio.fft (zignal/audio.py:678-704) as MLS_simple.plot_fft / examples/ex_mls.py:80
  * call it on the recovered response: window, DFT of fftsize points (n_samples, or n_samples+1 for the Mersenne-prime
- * sizes of audio.py:682-685), optional /fftsize, 20 log10 |Y|, bins 0..int(fftsize/2)-1. The DFT is hipFFT's
- * (loaded on first use); float64. */
+ * sizes of audio.py:682-685), optional /fftsize, 20 log10 |Y|, bins 0..int(fftsize/2)-1. The DFT is this library's own (csrc/fft.hip:
+ * power-of-two sizes directly, every other size as a Bluestein convolution fused into four to six passes; no FFT library is
+ * loaded); float64. */
 typedef struct zmls_spectrum zmls_spectrum;
 int zmls_spectrum_create(zmls_spectrum **out, int64_t n_samples, int64_t n_ch, int device);
 int zmls_spectrum_destroy(zmls_spectrum *s);

@@ -110,6 +110,11 @@ int zmls_host_lfsr_state(int N, const int32_t *taps, int ntaps, uint64_t steps, 
 /* enumerate the tile geometry of one pass and verify every element is covered exactly once per round and
  * every LDS slot / workspace row is in range; returns 0 if consistent. */
 int zmls_host_geometry_selfcheck(int K, int tile_cfg, int first_pass);
+/* the transform passes behind the magnitude response (csrc/fft_tile.h, fft.hip) run thread by thread on the CPU - the very
+ * code of the kernels - and held to a direct DFT. mode 0: forward passes of two transforms of `size` = 2^m points read back
+ * through the passes' own output order, then the inverse passes; mode 1: the whole Bluestein chain (chirp, forward, filter
+ * spectrum, inverse, chirp) for any `size` >= 2. size <= 2^23. Returns 0 when within 1e-11 of the largest bin. */
+int zmls_host_fft_selfcheck(int mode, int64_t size);
 
 /* the capture placement search of zmls_capture_alloc (zmls_host.cpp::placement_search) on a made-up machine: the
  * i-th buffer ever allocated is gathered in ms_of_alloc[i % n_ms] milliseconds and at most max_live buffers fit in

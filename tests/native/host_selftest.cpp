@@ -47,6 +47,9 @@ int main()
     for (int K = 10; K <= 11; ++K)
         for (int first = 0; first <= 1; ++first) CHECK(zmls_host_geometry_selfcheck(K, 3, first) == 0);
     CHECK(zmls_host_geometry_selfcheck(12, 3, 0) != 0 && zmls_host_geometry_selfcheck(3, 9, 0) == ZMLS_E_ARG);
+    // the transform passes of the magnitude response, thread by thread on the CPU, against a direct DFT
+    for (int m = 1; m <= 13; ++m) CHECK(zmls_host_fft_selfcheck(0, (int64_t)1 << m) == 0);
+    CHECK(zmls_host_fft_selfcheck(1, 1023) == 0 && zmls_host_fft_selfcheck(1, 5000) == 0 && zmls_host_fft_selfcheck(0, 1000) != 0);
     // GF(2) jump-ahead against the bit-serial register, orders 2..32 (32 exercises every shift at its limit)
     const struct { int N; int32_t taps[4]; int nt; } sets[] = {{2, {2, 1}, 2}, {3, {3, 2}, 2}, {16, {16, 15, 13, 4}, 4}, {20, {20, 17}, 2},
                                                                 {24, {24, 23, 22, 17}, 4}, {31, {31, 28}, 2}, {32, {32, 22, 2, 1}, 4}};

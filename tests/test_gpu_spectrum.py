@@ -68,7 +68,7 @@ def test_mls_simple_response_spectrum_is_the_emphasis_free_flat_line():
 
 
 def test_audio_fft_keeps_the_plan_of_a_shape_between_calls():
-    """Audio.fft (audio.py:678-704) used to build and destroy a hipFFT plan per call; the few most recent shapes are kept"""
+    """Audio.fft (audio.py:678-704) used to build and destroy a transform plan per call; the few most recent shapes are kept"""
     from zignal_amd import device as dev
     L = (1 << 12) - 1
     x = np.random.default_rng(3).standard_normal((L, 2))
@@ -101,3 +101,38 @@ def test_a_quiet_channel_beside_a_loud_one_keeps_its_accuracy():
             _, want = mls_oracle.audio_fft(h[:, c:c + 1], 96000, win or "rectangular", norm)
             check(mag[:, c:c + 1], want)              # 1e-12 x the channel's OWN largest bin
     sp.close()
+
+
+@pytest.mark.parametrize("n,ch", [(2, 1), (3, 2), (5, 1), (17, 3), (64, 2), (100, 2), (1000, 5), (4096, 2), (4097, 1), (8191, 2), (48000, 3),
+                                  (1 << 15, 4), (1 << 16, 1), (100003, 2), ((1 << 19) - 1, 2), (1 << 20, 2), ((1 << 21) - 1, 2), ((1 << 22) - 1, 1),
+                                  (3000000, 2)])
+def test_any_length_against_numpy(n, ch):
+    """Audio.fft works on whatever length the Audio holds (audio.py:680): powers of two run as forward passes whose output
+    order the dB kernel gathers from (one tile, one strided + one contiguous pass, two strided passes at 2^23 points), every
+    other length as the fused Bluestein chain - tiny ones with several transforms per tile, 2^22 - 1 with three passes each way."""
+    rng = np.random.default_rng(n)
+    h = rng.standard_normal((n, ch)) * np.exp(-np.arange(n) / max(4.0, n / 6.0))[:, None]
+    sp = Spectrum(n, ch, device=0)
+    assert sp.fftsize == n + (1 if n in (8191, (1 << 19) - 1) else 0)
+    for win, norm in ((None, False), ("hamming", True)):
+        import scipy.signal.windows
+        w = None if win is None else scipy.signal.windows.get_window(win, Nx=n)
+        _, want = mls_oracle.audio_fft(h, 48000, win or "rectangular", norm)
+        check(sp.magnitude_db_host(h, w, norm), want)
+    sp.close()
+
+
+def test_time_contiguous_responses_take_the_element_kernels():
+    """responses stacked channel by channel (ch_stride = L, row_stride = 1) go through the element-wise pack / dB kernels"""
+    from zignal_amd.device import DeviceBuffer
+    n, ch = (1 << 14) - 1, 3
+    rng = np.random.default_rng(5)
+    h = rng.standard_normal((n, ch)) * np.exp(-np.arange(n) / 900.0)[:, None]
+    sp = Spectrum(n, ch, device=0)
+    d_h = DeviceBuffer(n * ch * 8).upload(np.ascontiguousarray(h.T))
+    d_m = DeviceBuffer(sp.n_bins * ch * 8)
+    sp.magnitude_db_device(d_h.ptr, 1, n, None, False, d_m.ptr)
+    got = d_m.download((sp.n_bins, ch), np.float64)
+    _, want = mls_oracle.audio_fft(h, 48000, "rectangular", False)
+    check(got, want)
+    sp.close(); d_h.free(); d_m.free()

@@ -273,3 +273,19 @@ def test_plain_c_program_compiles_against_the_product_header_and_fails_loudly_wi
         assert r.returncode == 0 and "c_api ok" in r.stdout, r.stdout + r.stderr
     else:
         assert r.returncode == 3 and "no CPU path" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("m", list(range(1, 15)))
+def test_transform_passes_on_the_host_against_a_direct_dft(m):
+    """the tile code of csrc/fft_tile.h - the very functions the kernels call - run thread by thread on the CPU: forward passes
+    read back through the passes' own output order, then the inverse passes (2^13, 2^14: one strided + one contiguous level)"""
+    lib = _lib.lib()
+    assert lib.zmls_host_fft_selfcheck(0, 1 << m) == 0, _lib.last_error()
+
+
+@pytest.mark.parametrize("F", [2, 3, 5, 31, 100, 127, 1000, 1023, 2049, 4095, 8191, 16383, 48000])
+def test_bluestein_chain_on_the_host_against_a_direct_dft(F):
+    """chirp -> forward passes -> chirp filter's spectrum -> inverse passes -> chirp, for lengths that are not powers of two"""
+    lib = _lib.lib()
+    assert lib.zmls_host_fft_selfcheck(1, F) == 0, _lib.last_error()
+    assert lib.zmls_host_fft_selfcheck(0, 1000) != 0 and lib.zmls_host_fft_selfcheck(2, 8) != 0

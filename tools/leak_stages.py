@@ -3,7 +3,7 @@
 stage by stage, and the free device memory is compared before and after each stage. Measured (round 2): plans, captures,
 filters (incl. the fused scratch), loopback communicators, MLS / MLS_simple objects: +0 bytes once the first round of a
 stage has loaded what the runtime keeps (10 MiB of runtime staging once per process, 2 MiB once for the filter kernels);
-hipFFT plans: 25 MB once per set of sizes (the FFT library's own caches), not growing; RCCL communicators: about 19 MB stay
+spectra (hipFFT plans until round 3: 25 MB once per set of sizes inside that library; the library's own passes since: +0); RCCL communicators: about 19 MB stay
 with librccl after every ncclCommDestroy (inside the library, not in libzmls's buffers)."""
 import ctypes, os, sys, gc
 import numpy as np
@@ -38,7 +38,7 @@ def iir(i):
 stage("iir", iir, 300)
 def spec(i):
     s = Spectrum(4095 + 2 * (i % 3), 1 + i % 3, device=0); s.magnitude_db_host(np.ones((s.n_samples, s.n_ch))); s.close()
-stage("spectrum (hipFFT)", spec, 120)
+stage("spectrum", spec, 120)
 def comm(i):
     p = Plan(10, TAPS[10][0], device=0)
     c = multi.Comm(multi.make_unique_id(), 0, 1, device=0); multi.PeriodSharded(p, c, 8); c.close(); p.close()

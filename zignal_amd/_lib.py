@@ -106,6 +106,7 @@ SIGNATURES = {
     "zmls_host_pass_split": [c_int, ctypes.POINTER(c_int)],
     "zmls_host_lfsr_state": [c_int, _i32p, c_int, c_u64, ctypes.POINTER(ctypes.c_uint32)],
     "zmls_host_geometry_selfcheck": [c_int, c_int, c_int],
+    "zmls_host_fft_selfcheck": [c_int, c_i64],
     "zmls_host_placement_sim": [ctypes.POINTER(ctypes.c_float), c_int, c_int, c_int, ctypes.c_float, ctypes.POINTER(c_i64)],
     "zmls_dev_stream_probe": [c_int, c_vp, c_sz, c_int, c_vp],
 }

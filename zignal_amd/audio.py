@@ -135,7 +135,7 @@ class Audio(object):
 
     def fft(self, window='hann', normalise=True, device=None):
         """FFT magnitude of all channels in dB, up to fs/2: (frq, mag) as zignal/audio.py:678-704. The transform
-        runs on the GPU (zmls_spectrum_*: window, hipFFT, dB); window values and the frequency axis are host work."""
+        runs on the GPU (zmls_spectrum_*: window, this library's DFT passes, dB); window values and the frequency axis are host work."""
         import scipy.signal.windows
         from .device import spectrum_for
         sp = spectrum_for(self.nofsamples, self.ch, device=device)     # the plan of this shape is kept between calls

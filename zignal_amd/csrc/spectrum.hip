@@ -5,90 +5,34 @@
 // 2^13-1, 2^17-1, 2^19-1, 2^31-1, audio.py:682-685), optionally divide by fftsize, 20 log10 |Y|, keep bins
 // 0 .. int(fftsize/2)-1. Only the spectrum (half the response's size) then has to cross PCIe.
 //
-// The DFT itself is a plain library transform: hipFFT, loaded on first use. Around it two streaming kernels: window +
-// zero-pad + transpose into channel-major staging, and |Y| -> dB back into (bins, channels).
-// Even sizes (the bumped Mersenne sizes are powers of two): one double real-to-complex transform per channel.
-// Odd sizes (every other L = 2^N - 1: the library runs them as Bluestein convolutions on complex data, a real input
-// buys nothing): two channels ride in one complex transform, z = x1 + i x2, and come apart afterwards as
-// X1[k] = (Z[k] + conj Z[F-k]) / 2, X2[k] = (Z[k] - conj Z[F-k]) / 2i - half the transforms (N=20 x 64 channels: 12.6 -> 6.x ms).
+// The DFT is this library's own (fft.hip, fft_tile.h; round 3 - rounds 1 and 2 called hipFFT, which ran every L = 2^N - 1 as a
+// Bluestein convolution of thirteen kernels): power-of-two sizes (the bumped Mersenne sizes) as forward passes whose output
+// order the dB kernel gathers from, every other size as a Bluestein convolution fused into four passes. Around it two
+// streaming kernels: window + transpose into pair-major staging, and |Y| -> dB back into (bins, channels).
+// Two real channels ride in one complex transform, z = x1 + i x2, and come apart afterwards as
+// X1[k] = (Z[k] + conj Z[F-k]) / 2, X2[k] = (Z[k] - conj Z[F-k]) / 2i - half the transforms (a lone last channel rides with zeros).
 // The rounding error of one transform is relative to the larger of its two channels, so the second channel of a pair is first
 // brought to the level of the first by a power of two taken from the channels' peaks (exact, undone after the transform): a quiet
 // channel beside a loud one keeps the accuracy a transform of its own would give it (tests: channels 200 dB apart).
-#include <dlfcn.h>
 #include <algorithm>
 #include <stdlib.h>
 #include <string.h>
-#include <hipfft/hipfft.h>
 #include "zmls_internal.h"
+#include "fft_tile.h"
 
 namespace zmls {
+namespace fft {
+int forward(const Plan &p, PassArgs a, int load_mode, int store_mode, hipStream_t st, bool device);
+int inverse(const Plan &p, PassArgs a, int store_mode, hipStream_t st, bool device);
+}
 namespace {
 
-struct HipFft {
-    void *handle = nullptr;
-    hipfftResult (*PlanMany)(hipfftHandle *, int, int *, int *, int, int, int *, int, int, hipfftType, int) = nullptr;
-    hipfftResult (*SetStream)(hipfftHandle, hipStream_t) = nullptr;
-    hipfftResult (*ExecD2Z)(hipfftHandle, hipfftDoubleReal *, hipfftDoubleComplex *) = nullptr;
-    hipfftResult (*ExecZ2Z)(hipfftHandle, hipfftDoubleComplex *, hipfftDoubleComplex *, int) = nullptr;
-    hipfftResult (*Destroy)(hipfftHandle) = nullptr;
-    char why[256] = "";
-    bool ok = false;
-    HipFft()
-    {
-        const char *names[] = {"libhipfft.so.0", "libhipfft.so", "/opt/rocm/lib/libhipfft.so.0"};
-        for (const char *n : names) {
-            handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (handle) break;
-        }
-        if (!handle) { snprintf(why, sizeof why, "cannot load libhipfft: %s", dlerror()); return; }
-#define ZSYM(field, name)                                                                      \
-    field = (decltype(field))dlsym(handle, name);                                              \
-    if (!field) { snprintf(why, sizeof why, "libhipfft has no symbol %s", name); return; }
-        ZSYM(PlanMany, "hipfftPlanMany")
-        ZSYM(SetStream, "hipfftSetStream")
-        ZSYM(ExecD2Z, "hipfftExecD2Z")
-        ZSYM(ExecZ2Z, "hipfftExecZ2Z")
-        ZSYM(Destroy, "hipfftDestroy")
-#undef ZSYM
-        ok = true;
-    }
+// where bin k of a transform lies: natural order (Bluestein's output), or the forward passes' own order (power-of-two sizes)
+struct BinOrder {
+    int permuted;
+    fft::Plan plan;
 };
-
-HipFft *hipfft()
-{
-    static HipFft f;
-    if (!f.ok) { set_error("%s", f.why); return nullptr; }
-    return &f;
-}
-
-// stage[c][t] = h[t][c] * window[t] for t < n, 0 for n <= t < fftsize
-__global__ void __launch_bounds__(256) spectrum_prepare_kernel(const double *__restrict__ h, int64_t n, int64_t n_ch, int64_t row_stride,
-                                                               int64_t ch_stride, const double *__restrict__ window, int64_t fftsize,
-                                                               double *__restrict__ stage)
-{
-    const int64_t total = fftsize * n_ch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t c = idx / fftsize, t = idx - c * fftsize;
-        double v = 0.0;
-        if (t < n) {
-            v = h[t * row_stride + c * ch_stride];
-            if (window) v *= window[t];
-        }
-        stage[idx] = v;
-    }
-}
-
-// mag[k][c] = 20 log10(|Y[c][k]| * scale), k < n_bins
-__global__ void __launch_bounds__(256) spectrum_db_kernel(const double2 *__restrict__ Y, int64_t n_cplx, int64_t n_bins, int64_t n_ch, double scale,
-                                                          double *__restrict__ mag)
-{
-    const int64_t total = n_bins * n_ch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t c = idx / n_bins, k = idx - c * n_bins;
-        const double2 y = Y[c * n_cplx + k];
-        mag[k * n_ch + c] = 20.0 * log10(hypot(y.x, y.y) * scale);
-    }
-}
+__device__ __forceinline__ int64_t bin_at(const BinOrder &o, int64_t k) { return o.permuted ? (int64_t)fft::position_of(o.plan, (uint64_t)k) : k; }
 
 // packed mode: peak[c] = max_t |h[t][c] * window[t]| as the bit pattern of a non-negative double (ordered like the integers)
 __global__ void __launch_bounds__(256) spectrum_peak_kernel(const double *__restrict__ h, int64_t n, int64_t n_ch, int64_t row_stride,
@@ -139,12 +83,13 @@ __global__ void __launch_bounds__(256) spectrum_prepare_pairs_kernel(const doubl
 
 // packed mode: the two spectra of a pair from Z[k] and Z[F-k]
 __global__ void __launch_bounds__(256) spectrum_db_pairs_kernel(const double2 *__restrict__ Y, int64_t F, int64_t n_bins, int64_t n_ch, int64_t n_pairs,
-                                                                double scale, const unsigned long long *__restrict__ peak, double *__restrict__ mag)
+                                                                double scale, const unsigned long long *__restrict__ peak, double *__restrict__ mag,
+                                                                const BinOrder order)
 {
     const int64_t total = n_bins * n_pairs;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = idx / n_bins, k = idx - p * n_bins;
-        const double2 a = Y[p * F + k], b = Y[p * F + (k ? F - k : 0)];
+        const double2 a = Y[p * F + bin_at(order, k)], b = Y[p * F + bin_at(order, k ? F - k : 0)];
         // conj(b) = (b.x, -b.y):  X1 = (a + conj b) / 2,  |X2| = |a - conj b| / 2
         const double m1 = 0.5 * hypot(a.x + b.x, a.y - b.y), m2 = 0.5 * hypot(a.x - b.x, a.y + b.y);
         mag[k * n_ch + 2 * p] = 20.0 * log10(m1 * scale);
@@ -206,7 +151,8 @@ __global__ void __launch_bounds__(256) spectrum_prepare_pairs_rows_kernel(const 
 }
 
 __global__ void __launch_bounds__(256) spectrum_db_pairs_rows_kernel(const double2 *__restrict__ Y, int64_t F, int64_t n_bins, int64_t n_ch, int64_t n_pairs,
-                                                                     double scale, const unsigned long long *__restrict__ peak, double *__restrict__ mag)
+                                                                     double scale, const unsigned long long *__restrict__ peak, double *__restrict__ mag,
+                                                                     const BinOrder order)
 {
     __shared__ double tile[kSpT][kSpT + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -215,7 +161,7 @@ __global__ void __launch_bounds__(256) spectrum_db_pairs_rows_kernel(const doubl
         const int64_t p = c0 / 2 + pl, k = k0 + lane;
         double m1 = 0.0, m2 = 0.0;
         if (p < n_pairs && k < n_bins) {
-            const double2 a = Y[p * F + k], b = Y[p * F + (k ? F - k : 0)];
+            const double2 a = Y[p * F + bin_at(order, k)], b = Y[p * F + bin_at(order, k ? F - k : 0)];
             m1 = 0.5 * hypot(a.x + b.x, a.y - b.y);
             m2 = ldexp(0.5 * hypot(a.x - b.x, a.y + b.y), -pair_shift(peak, p, n_ch));
         }
@@ -239,12 +185,15 @@ bool mersenne_prime_size(int64_t n)
 
 struct zmls_spectrum {
     int device;
-    int64_t n, n_ch, fftsize, n_bins, n_cplx;
-    hipfftHandle plan;
-    int64_t n_pairs;        // > 0: packed mode (odd fftsize, two channels per complex transform)
-    double *d_stage;        // (n_ch, fftsize) real, or (n_pairs, fftsize) complex
-    double2 *d_Y;           // (n_ch, fftsize/2 + 1), or (n_pairs, fftsize)
-    unsigned long long *d_peak;   // packed mode: per-channel peak of the windowed samples (bit pattern of a double)
+    int64_t n, n_ch, fftsize, n_bins;
+    int64_t n_pairs;        // two channels per complex transform (the last one alone when n_ch is odd)
+    int bluestein;          // 0: fftsize is a power of two, forward passes only; 1: chirp-z on M = 2^m >= 2 fftsize - 1 points
+    zmls::fft::Plan plan;        // passes of the 2^m-point transform
+    double2 *d_stage;       // (n_pairs, n) windowed pairs
+    double2 *d_work;        // (n_pairs, 2^m) the transforms' array
+    double2 *d_Y;           // Bluestein: (n_pairs, fftsize) spectra in natural order (power of two: d_work in the passes' order)
+    double2 *d_table;       // Bluestein: spectrum of the chirp filter, 2^m points in the passes' order
+    unsigned long long *d_peak;   // per-channel peak of the windowed samples (bit pattern of a double)
 };
 
 using namespace zmls;
@@ -258,32 +207,40 @@ int zmls_spectrum_create(zmls_spectrum **out, int64_t n_samples, int64_t n_ch, i
     if (n_samples < 2 || n_ch < 1 || n_samples >= ((int64_t)1 << 31) - 1) { set_error("bad spectrum size"); return ZMLS_E_ARG; }
     ZDEVICE(device);
     int rc = ZMLS_OK;
-    HipFft *F = hipfft();
-    if (!F) return ZMLS_E_UNSUPPORTED;
     zmls_spectrum *s = (zmls_spectrum *)calloc(1, sizeof(zmls_spectrum));
     if (!s) { set_error("out of host memory"); return ZMLS_E_ARG; }
     s->device = device;
     s->n = n_samples; s->n_ch = n_ch;
     s->fftsize = n_samples + (mersenne_prime_size(n_samples) ? 1 : 0);      // audio.py:682-685
     s->n_bins = s->fftsize / 2;                                             // int(fftsize/2), audio.py:701-702
-    s->n_cplx = s->fftsize / 2 + 1;
-    s->n_pairs = ((s->fftsize & 1) && n_ch >= 2) ? (n_ch + 1) / 2 : 0;
-    hipError_t e = hipMalloc((void **)&s->d_stage, s->n_pairs ? (size_t)s->fftsize * s->n_pairs * 16 : (size_t)s->fftsize * n_ch * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_Y, s->n_pairs ? (size_t)s->fftsize * s->n_pairs * 16 : (size_t)s->n_cplx * n_ch * 16);
-    if (e == hipSuccess && s->n_pairs) e = hipMalloc((void **)&s->d_peak, (size_t)n_ch * 8);
+    s->n_pairs = (n_ch + 1) / 2;
+    s->bluestein = (s->fftsize & (s->fftsize - 1)) != 0;
+    int m = 1;
+    while (((int64_t)1 << m) < (s->bluestein ? 2 * s->fftsize - 1 : s->fftsize)) ++m;
+    s->plan = fft::make_plan(m);
+    const size_t M = (size_t)1 << m;
+    if ((((uint64_t)s->n_pairs << m) >> fft::kTileLog) > 0x7FFFFFFFull) {
+        free(s);
+        set_error("spectrum of %lld channels x %lld points: more than 2^31 tiles in one pass", (long long)n_ch, (long long)s->fftsize);
+        return ZMLS_E_UNSUPPORTED;
+    }
+    hipError_t e = hipMalloc((void **)&s->d_stage, (size_t)s->n * s->n_pairs * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_work, M * s->n_pairs * 16);
+    if (e == hipSuccess && s->bluestein) e = hipMalloc((void **)&s->d_Y, (size_t)s->fftsize * s->n_pairs * 16);
+    if (e == hipSuccess && s->bluestein) e = hipMalloc((void **)&s->d_table, M * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_peak, (size_t)n_ch * 8);
     if (e != hipSuccess) {
         rc = hip_fail(e, "spectrum buffers");
         (void)zmls_spectrum_destroy(s);
         return rc;
     }
-    int len[1] = {(int)s->fftsize};
-    hipfftResult r = s->n_pairs ? F->PlanMany(&s->plan, 1, len, nullptr, 1, (int)s->fftsize, nullptr, 1, (int)s->fftsize, HIPFFT_Z2Z, (int)s->n_pairs)
-                                : F->PlanMany(&s->plan, 1, len, nullptr, 1, (int)s->fftsize, nullptr, 1, (int)s->n_cplx, HIPFFT_D2Z, (int)n_ch);
-    if (r != HIPFFT_SUCCESS) {
-        set_error("hipfftPlanMany(%lld points x %lld) failed with %d", (long long)s->fftsize, (long long)n_ch, (int)r);
-        s->plan = 0;
-        (void)zmls_spectrum_destroy(s);
-        return ZMLS_E_HIP;
+    if (s->bluestein) {
+        // the chirp filter b[u] = exp(+i pi u^2 / F), |u| < F, wrapped around M: its spectrum, once per size, by the same passes
+        fft::PassArgs b{};
+        b.work = (fft::cd *)s->d_table; b.n_transforms = 1; b.F = (uint64_t)s->fftsize;
+        rc = fft::forward(s->plan, b, fft::LOAD_BSEQ, fft::STORE_WORK, nullptr, true);
+        if (!rc) { hipError_t es = hipStreamSynchronize(nullptr); if (es != hipSuccess) rc = hip_fail(es, "chirp filter spectrum"); }
+        if (rc) { (void)zmls_spectrum_destroy(s); return rc; }
     }
     *out = s;
     return ZMLS_OK;
@@ -294,10 +251,10 @@ int zmls_spectrum_destroy(zmls_spectrum *s)
     if (!s) return ZMLS_OK;
     DeviceScope on_device(s->device);
     if (!on_device.rc) {
-        HipFft *F = hipfft();
-        if (F && s->plan) (void)F->Destroy(s->plan);
         if (s->d_stage) (void)hipFree(s->d_stage);
+        if (s->d_work) (void)hipFree(s->d_work);
         if (s->d_Y) (void)hipFree(s->d_Y);
+        if (s->d_table) (void)hipFree(s->d_table);
         if (s->d_peak) (void)hipFree(s->d_peak);
     }
     free(s);
@@ -318,51 +275,50 @@ int zmls_spectrum_device(zmls_spectrum *s, const double *d_h, int64_t row_stride
     if (row_stride < 1 || ch_stride < 1) { set_error("strides must be positive"); return ZMLS_E_ARG; }
     ZDEVICE(s->device);
     int rc = ZMLS_OK;
-    HipFft *F = hipfft();
-    if (!F) return ZMLS_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     auto grid = [](int64_t n) { int64_t g = (n + 255) / 256; return (uint32_t)(g < 1 ? 1 : g > 65536 ? 65536 : g); };
-    if (s->n_pairs) {
-        // odd size: fftsize == n, nothing to pad
-        ZHIP(hipMemsetAsync(s->d_peak, 0, (size_t)s->n_ch * 8, st));
-        const uint32_t c_tiles = (uint32_t)((s->n_ch + kSpT - 1) / kSpT);
-        if (ch_stride == 1 && c_tiles <= 65535u) {
-            // frame-major responses: whole rows of adjacent channels on the response side, whole runs of frames / bins on the other
-            const int64_t rows_per_block = std::max<int64_t>(kSpT, (s->n + 4095) / 4096);
-            hipLaunchKernelGGL(spectrum_peak_rows_kernel, dim3((uint32_t)((s->n + rows_per_block - 1) / rows_per_block), c_tiles), dim3(256), 0, st, d_h, s->n,
-                               s->n_ch, row_stride, d_window, rows_per_block, s->d_peak);
-            hipLaunchKernelGGL(spectrum_prepare_pairs_rows_kernel, dim3((uint32_t)((s->n + kSpT - 1) / kSpT), c_tiles), dim3(256), 0, st, d_h, s->n, s->n_ch,
-                               row_stride, d_window, s->n_pairs, s->d_peak, (double2 *)s->d_stage);
-            ZHIP(hipGetLastError());
-            hipfftResult rq = F->SetStream(s->plan, st);
-            if (rq == HIPFFT_SUCCESS) rq = F->ExecZ2Z(s->plan, (hipfftDoubleComplex *)s->d_stage, (hipfftDoubleComplex *)s->d_Y, HIPFFT_FORWARD);
-            if (rq != HIPFFT_SUCCESS) { set_error("hipfftExecZ2Z failed with %d", (int)rq); return ZMLS_E_HIP; }
-            hipLaunchKernelGGL(spectrum_db_pairs_rows_kernel, dim3((uint32_t)((s->n_bins + kSpT - 1) / kSpT), c_tiles), dim3(256), 0, st, s->d_Y, s->fftsize,
-                               s->n_bins, s->n_ch, s->n_pairs, normalise ? 1.0 / (double)s->fftsize : 1.0, s->d_peak, d_mag);
-            ZHIP(hipGetLastError());
-            return ZMLS_OK;
-        }
+    ZHIP(hipMemsetAsync(s->d_peak, 0, (size_t)s->n_ch * 8, st));
+    const uint32_t c_tiles = (uint32_t)((s->n_ch + kSpT - 1) / kSpT);
+    // frame-major responses: whole rows of adjacent channels on the response side, whole runs of frames / bins on the other.
+    // Below eight channels a row is shorter than 64 bytes and the tile kernels would keep one lane in eight or fewer busy (one
+    // channel of 2^20 points: 253 us in them against 76 us in the four transform passes); frames on the lanes then.
+    const bool rows = ch_stride == 1 && s->n_ch >= 8 && c_tiles <= 65535u;
+    if (rows) {
+        const int64_t rows_per_block = std::max<int64_t>(kSpT, (s->n + 4095) / 4096);
+        hipLaunchKernelGGL(spectrum_peak_rows_kernel, dim3((uint32_t)((s->n + rows_per_block - 1) / rows_per_block), c_tiles), dim3(256), 0, st, d_h, s->n,
+                           s->n_ch, row_stride, d_window, rows_per_block, s->d_peak);
+        hipLaunchKernelGGL(spectrum_prepare_pairs_rows_kernel, dim3((uint32_t)((s->n + kSpT - 1) / kSpT), c_tiles), dim3(256), 0, st, d_h, s->n, s->n_ch,
+                           row_stride, d_window, s->n_pairs, s->d_peak, s->d_stage);
+    } else {
         hipLaunchKernelGGL(spectrum_peak_kernel, dim3(std::min<uint32_t>(grid(s->n), 1024u), (uint32_t)std::min<int64_t>(s->n_ch, 65535)), dim3(256), 0, st, d_h, s->n, s->n_ch,
                            row_stride, ch_stride, d_window, s->d_peak);
         hipLaunchKernelGGL(spectrum_prepare_pairs_kernel, dim3(grid(s->n * s->n_pairs)), dim3(256), 0, st, d_h, s->n, s->n_ch, row_stride, ch_stride,
-                           d_window, s->n_pairs, s->d_peak, (double2 *)s->d_stage);
-        ZHIP(hipGetLastError());
-        hipfftResult rp = F->SetStream(s->plan, st);
-        if (rp == HIPFFT_SUCCESS) rp = F->ExecZ2Z(s->plan, (hipfftDoubleComplex *)s->d_stage, (hipfftDoubleComplex *)s->d_Y, HIPFFT_FORWARD);
-        if (rp != HIPFFT_SUCCESS) { set_error("hipfftExecZ2Z failed with %d", (int)rp); return ZMLS_E_HIP; }
-        hipLaunchKernelGGL(spectrum_db_pairs_kernel, dim3(grid(s->n_bins * s->n_pairs)), dim3(256), 0, st, s->d_Y, s->fftsize, s->n_bins, s->n_ch, s->n_pairs,
-                           normalise ? 1.0 / (double)s->fftsize : 1.0, s->d_peak, d_mag);
-        ZHIP(hipGetLastError());
-        return ZMLS_OK;
+                           d_window, s->n_pairs, s->d_peak, s->d_stage);
     }
-    hipLaunchKernelGGL(spectrum_prepare_kernel, dim3(grid(s->fftsize * s->n_ch)), dim3(256), 0, st, d_h, s->n, s->n_ch, row_stride, ch_stride,
-                       d_window, s->fftsize, s->d_stage);
     ZHIP(hipGetLastError());
-    hipfftResult r = F->SetStream(s->plan, st);
-    if (r == HIPFFT_SUCCESS) r = F->ExecD2Z(s->plan, s->d_stage, (hipfftDoubleComplex *)s->d_Y);
-    if (r != HIPFFT_SUCCESS) { set_error("hipfftExecD2Z failed with %d", (int)r); return ZMLS_E_HIP; }
-    hipLaunchKernelGGL(spectrum_db_kernel, dim3(grid(s->n_bins * s->n_ch)), dim3(256), 0, st, s->d_Y, s->n_cplx, s->n_bins, s->n_ch,
-                       normalise ? 1.0 / (double)s->fftsize : 1.0, d_mag);
+    // the transforms: samples beyond n (the size bump) and beyond fftsize (Bluestein's padding) are zeros the first pass makes up
+    fft::PassArgs a{};
+    a.work = (fft::cd *)s->d_work; a.n_transforms = (uint64_t)s->n_pairs;
+    a.stage = (const fft::cd *)s->d_stage; a.n_stage = (uint64_t)s->n; a.F = (uint64_t)s->fftsize;
+    BinOrder order{};
+    const double2 *Y = s->d_work;
+    if (s->bluestein) {
+        a.table = (const fft::cd *)s->d_table; a.Y = (fft::cd *)s->d_Y; a.scale = ldexp(1.0, -s->plan.m);
+        rc = fft::forward(s->plan, a, fft::LOAD_STAGE_CHIRP, fft::STORE_WORK_TIMES_TABLE, st, true);
+        if (!rc) rc = fft::inverse(s->plan, a, fft::STORE_FINAL_CHIRP, st, true);
+        Y = s->d_Y;
+    } else {
+        rc = fft::forward(s->plan, a, fft::LOAD_STAGE, fft::STORE_WORK, st, true);
+        order.permuted = 1; order.plan = s->plan;
+    }
+    if (rc) return rc;
+    const double scale = normalise ? 1.0 / (double)s->fftsize : 1.0;
+    if (rows)
+        hipLaunchKernelGGL(spectrum_db_pairs_rows_kernel, dim3((uint32_t)((s->n_bins + kSpT - 1) / kSpT), c_tiles), dim3(256), 0, st, Y, s->fftsize,
+                           s->n_bins, s->n_ch, s->n_pairs, scale, s->d_peak, d_mag, order);
+    else
+        hipLaunchKernelGGL(spectrum_db_pairs_kernel, dim3(grid(s->n_bins * s->n_pairs)), dim3(256), 0, st, Y, s->fftsize, s->n_bins, s->n_ch, s->n_pairs,
+                           scale, s->d_peak, d_mag, order);
     ZHIP(hipGetLastError());
     return ZMLS_OK;
 }

@@ -373,8 +373,8 @@ _SPECTRA_KEPT = 4
 
 
 def spectrum_for(n_samples, n_ch=1, device=None):
-    """The Spectrum (hipFFT plan + device buffers) for this shape, kept between calls: building a Bluestein plan for L = 2^N - 1
-    points costs more than the transform it then runs (Audio.fft used to build and destroy one per call). The few most recently
+    """The Spectrum (device buffers + the chirp filter's spectrum, itself one forward transform) for this shape, kept between calls:
+    setting one up for L = 2^N - 1 points costs more than the transform it then runs (Audio.fft used to build and destroy one per call). The few most recently
     used shapes stay; the one that falls out is closed."""
     dev = L.default_device() if device is None else int(device)
     key = (int(n_samples), int(n_ch), dev)
