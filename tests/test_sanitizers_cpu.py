@@ -23,14 +23,14 @@ def test_oracle_c_under_asan_and_ubsan(tmp_path):
 
 
 def test_library_host_logic_under_asan_and_ubsan(tmp_path):
-    """zmls_host.cpp (error text, GF(2) jump tables, pass planner, tile geometry check, placement search) with the
+    """zmls_host.cpp (error text, GF(2) jump tables, pass planner, tile geometry check, placement search, and the transform passes of fft.hip run on the host) with the
     argument checks of api.hip in front of it; sanitizers on the host side only (-Xarch_host)."""
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
     exe = str(tmp_path / "host_selftest")
     src = os.path.join(ROOT, "zignal_amd", "csrc")
     files = [os.path.join(src, f) for f in ("zmls_host.cpp", "api.hip", "lfsr.hip", "fwht_f64.hip", "fwht_f32.hip", "period_sum.hip",
-                                             "layout.hip", "static_ws.hip", "hostcopy.hip")]
+                                             "layout.hip", "static_ws.hip", "hostcopy.hip", "fft.hip")]
     cmd = [HIPCC, "-O1", "-g", "-std=c++17", "--offload-arch=gfx950", "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
            "-Xarch_host", "-fno-sanitize-recover=all", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-x", "hip"] + files + \
           [os.path.join(ROOT, "tests", "native", "host_selftest.cpp"), "-o", exe]
