@@ -67,6 +67,18 @@ void emulate_pass_tiles(const PassArgs &a, uint64_t n_tiles)
 
 uint64_t tiles_of(const PassArgs &a) { return (a.total + kTile - 1) >> kTileLog; }
 
+// exp(-i pi i^2 d^2 / F), i = 0..15, for the distance d between a thread's points in this pass (fft_tile.h::ThreadPoints)
+void chirp_pass_constants(PassArgs &a)
+{
+    const uint64_t d = a.lv.strided ? (uint64_t)(kThreads >> (kTileLog - a.lv.K)) << a.lv.logC : (uint64_t)kThreads;
+    for (int i = 0; i < kPerThread; ++i) {
+        const unsigned __int128 x = (unsigned __int128)d * d * (unsigned)(i * i);
+        const uint64_t r = (uint64_t)(x % (unsigned __int128)(2 * a.F));
+        const long double ang = -3.14159265358979323846264338327950288L * (long double)r / (long double)a.F;
+        a.chirp_i2[i] = cd{(double)cosl(ang), (double)sinl(ang)};
+    }
+}
+
 // device == false: the same passes on the host (zmls_host_fft_selfcheck)
 int run_pass(const PassArgs &a, hipStream_t st, bool device)
 {
@@ -105,6 +117,7 @@ int forward(const Plan &p, PassArgs a, int load_mode, int store_mode, hipStream_
         a.lv = p.level[i];
         a.load_mode = i == 0 ? load_mode : LOAD_WORK;
         a.store_mode = i == p.n_levels - 1 ? store_mode : STORE_WORK;
+        if (a.load_mode == LOAD_STAGE_CHIRP) chirp_pass_constants(a);
         if (int rc = run_pass(a, st, device)) return rc;
     }
     return ZMLS_OK;
@@ -117,6 +130,7 @@ int inverse(const Plan &p, PassArgs a, int store_mode, hipStream_t st, bool devi
         a.lv = p.level[i];
         a.load_mode = LOAD_WORK;
         a.store_mode = i == 0 ? store_mode : STORE_WORK;
+        if (a.store_mode == STORE_FINAL_CHIRP) chirp_pass_constants(a);
         if (int rc = run_pass(a, st, device)) return rc;
     }
     return ZMLS_OK;

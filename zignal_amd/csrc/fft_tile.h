@@ -57,10 +57,12 @@ ZFD cd unit_neg(double t)
 }
 
 ZFD constexpr int num_rounds(int K) { return K <= 4 ? 1 : K <= 8 ? 2 : 3; }
+// radix 16 first: every round but the last multiplies by twiddles - one sincospi per butterfly - and a radix-16 round has one
+// butterfly per thread where two radix-8 rounds have two each (9 bits: 4 + 4 + 1, not 3 + 3 + 3)
 ZFD constexpr int round_bits(int K, int rho)
 {
-    const int nr = num_rounds(K);
-    return K / nr + (rho < K % nr ? 1 : 0);
+    const int left = K - 4 * rho;
+    return left > 4 ? 4 : left;
 }
 // weight (log2) of round rho's digit inside the in-place row position: the bits of the rounds after it
 ZFD constexpr int round_weight_log(int K, int rho)
@@ -308,19 +310,10 @@ ZFD uint64_t mod_2F(uint64_t x, uint64_t F)
 ZFD cd chirp_root(uint64_t j, uint64_t F) { return unit_neg((double)j / (double)F); }
 // Bluestein's chirp exp(-i pi t^2 / F): t^2 mod 2F exactly in integers (t < 2^31), then one unit root
 ZFD cd chirp(uint64_t t, uint64_t F) { return chirp_root(mod_2F(t * t, F), F); }
-// ... along t = t0 + i d, i = 0, 1, 2, ...: c(t + d) = c(t) g, g -> g b2 with g = exp(-i pi (2 t d + d^2) / F), b2 = exp(-2 i pi d^2 / F):
-// three unit roots where the points start, two complex products per point after that (t0 < 2^31, d <= 2^28)
-struct ChirpSeq { cd c, g, b2; };
-ZFD ChirpSeq chirp_seq(uint64_t t0, uint64_t d, uint64_t F)
-{
-    ChirpSeq q;
-    const uint64_t td = mod_2F(t0 * d, F), dd = mod_2F(d * d, F);
-    q.c = chirp(t0, F);
-    q.g = chirp_root(mod_2F(2 * td + dd, F), F);
-    q.b2 = chirp_root(mod_2F(2 * dd, F), F);
-    return q;
-}
-ZFD void chirp_next(ChirpSeq &q) { q.c = cmul(q.c, q.g); q.g = cmul(q.g, q.b2); }
+// ... along t = t0 + i d, i = 0..15: c(t0 + i d) = c(t0) A^i B^(i^2) with A = exp(-2 i pi t0 d / F) (one unit root per thread, its
+// powers by for_twiddle_sequence) and B^(i^2) = exp(-i pi i^2 d^2 / F), sixteen constants of the PASS (d is the same for every
+// thread of a pass) that the host computes in long double (chirp_pass_constants) and hands over with the kernel arguments.
+ZFD cd chirp_ratio(uint64_t t0, uint64_t d, uint64_t F) { return chirp_root(mod_2F(2 * mod_2F(t0 * d, F), F), F); }
 
 // ---- one pass = every tile through: load -> rounds -> store. The phases are separate functions of (tile, thread) so that the
 // device kernel (barriers in between) and the host emulation (a loop over the threads per phase) run the very same code.
@@ -340,6 +333,7 @@ struct PassArgs {
     const cd *table;            // STORE_WORK_TIMES_TABLE: M points (the chirp filter's spectrum, in the passes' own order)
     cd *Y;                      // STORE_FINAL_CHIRP: F points per transform
     double scale;
+    cd chirp_i2[kPerThread];    // chirp passes: exp(-i pi i^2 d^2 / F) for the pass's point distance d (chirp_pass_constants)
 };
 
 ZFD cd pass_load_point(const PassArgs &a, uint64_t g)
@@ -373,8 +367,8 @@ ZFD void pass_store_point(const PassArgs &a, uint64_t g, cd v)
 
 // The 16 points of a thread, e = i * 256 + tid. From 2^12 points up a tile lies inside one transform and those points are an
 // arithmetic progression there - contiguous tile: 256 apart; strided tile (K >= 4, so S <= 256): one column, rows 2^(K-4) apart -
-// so the level's twiddles are base * step^i and the chirp runs as chirp_seq (two fresh starts per thread, at i = 0 and 8, keep
-// the accumulated rounding at a few ulp) instead of one sincospi and one modular square per point.
+// so the level's twiddles are base * step^i and the chirp is c(t0) A^i times sixteen constants of the pass (chirp_ratio) instead of
+// one sincospi and one modular square per point.
 template <int K, bool STRIDED>
 struct ThreadPoints {
     static constexpr int LOGS = kTileLog - K;
@@ -454,17 +448,9 @@ ZFD void phase_load(const PassArgs &a, const TileAt &at, uint32_t tid, cd *lds)
             const uint64_t t = tp.pos0 + (uint64_t)i * tp.step;
             v[i] = t < a.n_stage ? src[t] : cd{0.0, 0.0};
         }
-        if (a.load_mode == LOAD_STAGE_CHIRP && tp.pos0 < a.n_stage) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                ChirpSeq q = chirp_seq(tp.pos0 + (uint64_t)(half * 8) * tp.step, tp.step, a.F);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    v[half * 8 + i] = cmul(v[half * 8 + i], q.c);
-                    if (i < 7) chirp_next(q);
-                }
-            }
-        }
+        if (a.load_mode == LOAD_STAGE_CHIRP && tp.pos0 < a.n_stage)
+            for_twiddle_sequence(chirp(tp.pos0, a.F), chirp_ratio(tp.pos0, tp.step, a.F),
+                                 [&](int i, cd w) { v[i] = cmul(v[i], cmul(w, a.chirp_i2[i])); });
     }
     if (a.inv) {
 #pragma unroll
@@ -516,18 +502,12 @@ ZFD void phase_store(const PassArgs &a, const TileAt &at, uint32_t tid, const cd
         for (int i = 0; i < kPerThread; ++i) a.work[tp.g0 + (uint64_t)i * tp.step] = cmul(v[i], w[i]);
     } else if (tp.pos0 < a.F) {
         cd *dst = a.Y + tp.tr * a.F;
+        for_twiddle_sequence(chirp(tp.pos0, a.F), chirp_ratio(tp.pos0, tp.step, a.F),
+                             [&](int i, cd w) { v[i] = cmul(v[i], cmul(w, a.chirp_i2[i])); });
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            ChirpSeq q = chirp_seq(tp.pos0 + (uint64_t)(half * 8) * tp.step, tp.step, a.F);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint64_t t = tp.pos0 + (uint64_t)(half * 8 + i) * tp.step;
-                if (t < a.F) {
-                    const cd o = cmul(v[half * 8 + i], q.c);
-                    dst[t] = cd{o.x * a.scale, o.y * a.scale};
-                }
-                if (i < 7) chirp_next(q);
-            }
+        for (int i = 0; i < kPerThread; ++i) {
+            const uint64_t t = tp.pos0 + (uint64_t)i * tp.step;
+            if (t < a.F) dst[t] = cd{v[i].x * a.scale, v[i].y * a.scale};
         }
     }
 }
