@@ -136,3 +136,19 @@ def test_time_contiguous_responses_take_the_element_kernels():
     _, want = mls_oracle.audio_fft(h, 48000, "rectangular", False)
     check(got, want)
     sp.close(); d_h.free(); d_m.free()
+
+
+def test_a_response_of_fifty_million_points():
+    """three levels each way (n = 3 x 2^24, a length numpy transforms quickly; M = 2^27 as 8 + 7 + 12 bits), offsets beyond 2^31 bytes
+    inside one transform"""
+    n = 3 << 24
+    rng = np.random.default_rng(26)
+    h = (rng.standard_normal(n) * np.exp(-np.arange(n) / 2.0e6)).reshape(-1, 1)
+    sp = Spectrum(n, 1, device=0)
+    mag = sp.magnitude_db_host(h, None, False)
+    sp.close()
+    want = 20.0 * np.log10(np.abs(np.fft.fft(h[:, 0])[:n // 2]))
+    assert mag.shape == (n // 2, 1)
+    check(mag[::4099], want[::4099].reshape(-1, 1))
+    peak = np.max(lin(want))
+    assert np.max(np.abs(lin(mag[:, 0]) - lin(want))) <= 1e-12 * peak
