@@ -177,12 +177,30 @@ int zmls_host_fft_selfcheck(int mode, int64_t size)
         fft::PassArgs a{};
         a.work = w.data(); a.n_transforms = nt;
         if (int rc = forward(p, a, LOAD_WORK, STORE_WORK, nullptr, false)) return rc;
+        // reference: textbook radix-2 (bit reversal, then log2 M butterfly sweeps) in double, every bin; a direct DFT for tiny sizes
         double peak = 0, worst = 0;
-        const uint64_t step = M <= 512 ? 1 : M <= 65536 ? M / 257 : M / 29;
         for (uint64_t tr = 0; tr < nt; ++tr) {
-            std::vector<cd> one(x.begin() + tr * M, x.begin() + (tr + 1) * M);
-            for (uint64_t k = 0; k < M; k += step) {
-                const cd want = direct(one, M, k), got = w[tr * M + position_of(p, k)];
+            std::vector<cd> ref(x.begin() + tr * M, x.begin() + (tr + 1) * M);
+            if (M <= 64) {
+                const std::vector<cd> one = ref;
+                for (uint64_t k = 0; k < M; ++k) ref[k] = direct(one, M, k);
+            } else {
+                for (uint64_t i = 0; i < M; ++i) {
+                    const uint64_t j = bit_reverse((uint32_t)i, m);
+                    if (j > i) std::swap(ref[i], ref[j]);
+                }
+                for (uint64_t half = 1; half < M; half <<= 1)
+                    for (uint64_t k = 0; k < half; ++k) {
+                        const long double ang = -3.14159265358979323846264338327950288L * (long double)k / (long double)half;
+                        const cd w{(double)cosl(ang), (double)sinl(ang)};
+                        for (uint64_t b0 = k; b0 < M; b0 += 2 * half) {
+                            const cd u = ref[b0], t = cmul(ref[b0 + half], w);
+                            ref[b0] = u + t; ref[b0 + half] = u - t;
+                        }
+                    }
+            }
+            for (uint64_t k = 0; k < M; ++k) {
+                const cd want = ref[k], got = w[tr * M + position_of(p, k)];
                 peak = fmax(peak, hypot(want.x, want.y));
                 worst = fmax(worst, hypot(got.x - want.x, got.y - want.y));
             }
