@@ -84,9 +84,15 @@ int run_pass(const PassArgs &a, hipStream_t st, bool device)
 {
     const uint64_t n_tiles = tiles_of(a);
     if (n_tiles == 0 || n_tiles > 0x7FFFFFFFull) { set_error("transform pass grid out of range (%llu tiles)", (unsigned long long)n_tiles); return ZMLS_E_ARG; }
+// -DZMLS_FFT_NO_DEVICE (the sanitizer build of the host logic, tests/test_sanitizers_cpu.py): no kernel is instantiated
+#ifdef ZMLS_FFT_NO_DEVICE
+#define ZFFT_LAUNCH(KK, ST) do { set_error("built without the transform kernels"); return ZMLS_E_UNSUPPORTED; } while (0)
+#else
+#define ZFFT_LAUNCH(KK, ST) hipLaunchKernelGGL((fft_pass_kernel<KK, ST>), dim3((uint32_t)n_tiles), dim3(kThreads), 0, st, a)
+#endif
 #define ZFFT_CASE(KK, ST)                                                                                              \
     case KK:                                                                                                           \
-        if (device) hipLaunchKernelGGL((fft_pass_kernel<KK, ST>), dim3((uint32_t)n_tiles), dim3(kThreads), 0, st, a);   \
+        if (device) ZFFT_LAUNCH(KK, ST);                                                                               \
         else emulate_pass_tiles<KK, ST>(a, n_tiles);                                                                   \
         break;
     if (a.lv.strided) {
@@ -102,6 +108,7 @@ int run_pass(const PassArgs &a, hipStream_t st, bool device)
         }
     }
 #undef ZFFT_CASE
+#undef ZFFT_LAUNCH
     if (device) ZHIP(hipGetLastError());
     return ZMLS_OK;
 }
