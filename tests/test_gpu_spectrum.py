@@ -152,3 +152,17 @@ def test_a_response_of_fifty_million_points():
     check(mag[::4099], want[::4099].reshape(-1, 1))
     peak = np.max(lin(want))
     assert np.max(np.abs(lin(mag[:, 0]) - lin(want))) <= 1e-12 * peak
+
+
+def test_more_pairs_than_go_through_the_passes_at_once():
+    """Bluestein runs 256 MiB of transforms at a time (N=16: 128 pairs of 2^17 points): 300 channels are two chunks, the
+    second one short"""
+    n, ch = (1 << 16) - 1, 300
+    rng = np.random.default_rng(300)
+    h = rng.standard_normal((n, ch)) * np.exp(-np.arange(n) / 4000.0)[:, None] * (1.0 + np.arange(ch))[None, :]
+    sp = Spectrum(n, ch, device=0)
+    mag = sp.magnitude_db_host(h, None, True)
+    sp.close()
+    for c in (0, 1, 127, 255, 256, 257, 298, 299):
+        _, want = mls_oracle.audio_fft(h[:, c:c + 1], 48000, "rectangular", True)
+        check(mag[:, c:c + 1], want)

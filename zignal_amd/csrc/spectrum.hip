@@ -102,6 +102,8 @@ __global__ void __launch_bounds__(256) spectrum_db_pairs_kernel(const double2 *_
 // 64 x 64 tile crosses LDS in between and both sides move whole 512-byte rows. (One element per lane with frames on the lanes
 // read 8 bytes out of every 512: the three kernels took 36 % of the call, profiles/r03_spectrum_kernel_stats.csv.)
 constexpr int kSpT = 64;            // frames (bins) and channels per tile
+// (measured, profiles/r03_spectrum_own_fft.txt: 256 MiB best of 32 ... 512 MiB and all at once)
+constexpr size_t kSpectrumChunkBytes = (size_t)256 << 20;
 
 __global__ void __launch_bounds__(256) spectrum_peak_rows_kernel(const double *__restrict__ h, int64_t n, int64_t n_ch, int64_t row_stride,
                                                                  const double *__restrict__ window, int64_t rows_per_block,
@@ -187,10 +189,11 @@ struct zmls_spectrum {
     int device;
     int64_t n, n_ch, fftsize, n_bins;
     int64_t n_pairs;        // two channels per complex transform (the last one alone when n_ch is odd)
+    int64_t chunk_pairs;    // Bluestein: pairs that go through the passes together (the work array holds that many transforms)
     int bluestein;          // 0: fftsize is a power of two, forward passes only; 1: chirp-z on M = 2^m >= 2 fftsize - 1 points
     zmls::fft::Plan plan;        // passes of the 2^m-point transform
     double2 *d_stage;       // (n_pairs, n) windowed pairs
-    double2 *d_work;        // (n_pairs, 2^m) the transforms' array
+    double2 *d_work;        // (n_pairs, 2^m) the transforms' array; Bluestein: (chunk_pairs, 2^m)
     double2 *d_Y;           // Bluestein: (n_pairs, fftsize) spectra in natural order (power of two: d_work in the passes' order)
     double2 *d_table;       // Bluestein: spectrum of the chirp filter, 2^m points in the passes' order
     unsigned long long *d_peak;   // per-channel peak of the windowed samples (bit pattern of a double)
@@ -224,8 +227,15 @@ int zmls_spectrum_create(zmls_spectrum **out, int64_t n_samples, int64_t n_ch, i
         set_error("spectrum of %lld channels x %lld points: more than 2^31 tiles in one pass", (long long)n_ch, (long long)s->fftsize);
         return ZMLS_E_UNSUPPORTED;
     }
+    // Bluestein runs a chunk of pairs through its four passes before the next chunk: work array of kSpectrumChunkBytes (one pair
+    // at least) instead of n_pairs x 2^m points (N=20 x 64 channels: 256 MiB instead of 1 GiB)
+    static const size_t chunk_bytes = [] {
+        const char *v = getenv("ZMLS_SPECTRUM_CHUNK_MIB");          // tuning
+        return (v && *v) ? (size_t)strtoull(v, nullptr, 10) << 20 : kSpectrumChunkBytes;
+    }();
+    s->chunk_pairs = s->bluestein ? std::max<int64_t>(1, std::min<int64_t>(s->n_pairs, (int64_t)(chunk_bytes / (M * 16)))) : s->n_pairs;
     hipError_t e = hipMalloc((void **)&s->d_stage, (size_t)s->n * s->n_pairs * 16);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_work, M * s->n_pairs * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_work, M * (size_t)s->chunk_pairs * 16);
     if (e == hipSuccess && s->bluestein) e = hipMalloc((void **)&s->d_Y, (size_t)s->fftsize * s->n_pairs * 16);
     if (e == hipSuccess && s->bluestein) e = hipMalloc((void **)&s->d_table, M * 16);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_peak, (size_t)n_ch * 8);
@@ -303,9 +313,16 @@ int zmls_spectrum_device(zmls_spectrum *s, const double *d_h, int64_t row_stride
     BinOrder order{};
     const double2 *Y = s->d_work;
     if (s->bluestein) {
-        a.table = (const fft::cd *)s->d_table; a.Y = (fft::cd *)s->d_Y; a.scale = ldexp(1.0, -s->plan.m);
-        rc = fft::forward(s->plan, a, fft::LOAD_STAGE_CHIRP, fft::STORE_WORK_TIMES_TABLE, st, true);
-        if (!rc) rc = fft::inverse(s->plan, a, fft::STORE_FINAL_CHIRP, st, true);
+        // a few pairs at a time through all four passes: the work array is only that large, and what one pass writes the next
+        // reads back from the Infinity Cache (zmls_spectrum_create)
+        a.table = (const fft::cd *)s->d_table; a.scale = ldexp(1.0, -s->plan.m);
+        for (int64_t p0 = 0; p0 < s->n_pairs && !rc; p0 += s->chunk_pairs) {
+            a.n_transforms = (uint64_t)std::min(s->chunk_pairs, s->n_pairs - p0);
+            a.stage = (const fft::cd *)s->d_stage + p0 * s->n;
+            a.Y = (fft::cd *)s->d_Y + p0 * s->fftsize;
+            rc = fft::forward(s->plan, a, fft::LOAD_STAGE_CHIRP, fft::STORE_WORK_TIMES_TABLE, st, true);
+            if (!rc) rc = fft::inverse(s->plan, a, fft::STORE_FINAL_CHIRP, st, true);
+        }
         Y = s->d_Y;
     } else {
         rc = fft::forward(s->plan, a, fft::LOAD_STAGE, fft::STORE_WORK, st, true);
