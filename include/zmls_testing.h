@@ -100,6 +100,12 @@ int zmls_iir_set_segment(zmls_iir *f, size_t bytes);
  * middle passes, out[2] last (scatter) pass. The cache-resident schedule runs a step as many chunk launches; a profile's
  * per-launch counters times these counts are the step's (tools/summarize_profile.py). No reference counterpart. */
 int zmls_plan_last_launches(const zmls_plan *p, int32_t out[3]);
+/* one-launch schedule of two-pass orders (tuning flag 8 of zmls_plan_set_resident): out[0] = tickets taken by the last launch (twice
+ * the tiles of a pass when all is well), out[1] = 1 if a workgroup gave up waiting for its slab's gather tiles (its tile was skipped:
+ * the responses are then incomplete). Synchronises the device. zmls_plan_set_pipeline_delay: tiles by which the scatter tiles trail the
+ * gather tiles beyond one slab (0: default 768). No reference counterpart. */
+int zmls_plan_pipeline_status(zmls_plan *p, int32_t out[2]);
+int zmls_plan_set_pipeline_delay(zmls_plan *p, uint32_t extra_tiles);
 
 /* ---- host-only helpers (no GPU needed; used by the CPU test tier) */
 /* how a 2^N-point transform is split into LDS-resident passes: bits[i] for i < returned count */

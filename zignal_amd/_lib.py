@@ -105,6 +105,8 @@ SIGNATURES = {
     "zmls_plan_import_table": [c_vp, c_int, c_vp],
     "zmls_host_pass_split": [c_int, ctypes.POINTER(c_int)],
     "zmls_host_lfsr_state": [c_int, _i32p, c_int, c_u64, ctypes.POINTER(ctypes.c_uint32)],
+    "zmls_plan_pipeline_status": [c_vp, ctypes.POINTER(ctypes.c_int32)],
+    "zmls_plan_set_pipeline_delay": [c_vp, ctypes.c_uint32],
     "zmls_host_geometry_selfcheck": [c_int, c_int, c_int],
     "zmls_host_fft_selfcheck": [c_int, c_i64],
     "zmls_host_placement_sim": [ctypes.POINTER(ctypes.c_float), c_int, c_int, c_int, ctypes.c_float, ctypes.POINTER(c_i64)],

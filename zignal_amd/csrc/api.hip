@@ -83,6 +83,7 @@ __global__ void count_sentinels_kernel(const uint32_t *t, uint64_t n, unsigned l
 }
 
 size_t slab_bytes(const zmls_plan *p, int cfg) { return (size_t)work_rows_total(p->N) * (kVecBytes << kCfg[cfg].lu); }
+static inline uint64_t U0(const TileCfg &tc) { return 1ull << tc.lu; }
 int chans_per_slab(const zmls_plan *p, int cfg) { return (int)((kVecBytes << kCfg[cfg].lu) / dtype_size(p->dtype)); }
 
 void free_plan_buffers(zmls_plan *p)
@@ -95,6 +96,7 @@ void free_plan_buffers(zmls_plan *p)
     if (p->d_jt) (void)hipFree(p->d_jt);
     if (p->d_work) (void)hipFree(p->d_work);
     if (p->aux_stream) { (void)hipStreamDestroy(p->aux_stream); (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join); }
+    if (p->d_pipe) (void)hipFree(p->d_pipe);
     for (int i = 0; i < 2; ++i) {
         if (p->d_stage[i]) (void)hipFree(p->d_stage[i]);
         if (p->d_host_call[i]) (void)hipFree(p->d_host_call[i]);
@@ -335,9 +337,35 @@ int zmls_plan_set_resident(zmls_plan *p, int mode, size_t bytes, int flags)
         ZHIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
         ZHIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     }
+    if ((flags & 8) && !p->d_pipe) {
+        ZDEVICE(p->device);
+        int rc = ZMLS_OK;
+        ZHIP(hipMalloc((void **)&p->d_pipe, (size_t)(4 + kPipeMaxSlabs) * sizeof(uint32_t)));
+    }
     p->resident_mode = mode;
     p->resident_bytes = bytes;
     p->resident_flags = flags;
+    return ZMLS_OK;
+}
+
+int zmls_plan_set_pipeline_delay(zmls_plan *p, uint32_t extra_tiles)
+{
+    if (!p) { set_error("null argument"); return ZMLS_E_ARG; }
+    p->pipe_delay = extra_tiles;
+    return ZMLS_OK;
+}
+
+int zmls_plan_pipeline_status(zmls_plan *p, int32_t out[2])
+{
+    if (!p || !out) { set_error("null argument"); return ZMLS_E_ARG; }
+    out[0] = out[1] = 0;
+    if (!p->d_pipe) return ZMLS_OK;
+    ZDEVICE(p->device);
+    int rc = ZMLS_OK;
+    uint32_t w[2];
+    ZHIP(hipDeviceSynchronize());
+    ZHIP(hipMemcpy(w, p->d_pipe, sizeof w, hipMemcpyDeviceToHost));
+    out[0] = (int32_t)w[0]; out[1] = (int32_t)w[1];
     return ZMLS_OK;
 }
 
@@ -631,6 +659,50 @@ int run_passes(zmls_plan *p, const void *d_x, int in_dtype, int64_t periods, int
     const bool want_resident = p->work_layout == 0 && (p->resident_mode > 0 || (p->resident_mode < 0 && periods <= kResidentMaxPeriods));
     const bool resident2 = want_resident && npass == 2 && sbytes <= budget;       // (the placement probe's lone gather pass runs in the same chunks)
     const bool resident3 = want_resident && !gather_pass_only && npass == 3 && pass_bits[1] >= log2_tiles(pass_bits[0], tc) && pass_bits[0] >= log2_tiles(pass_bits[1], tc);
+    // One launch for both passes (tuning flag 8; fwht_kernels.inc::fwht_pipeline_kernel): wide vector-aligned batches of a two-pass
+    // order on the mid tile whose intermediate fits the workspace slab by slab (nothing is written twice within the launch).
+    if (want_resident && (p->resident_flags & 8) && p->d_pipe && npass == 2 && !pc && !gather_pass_only && cfg == CFG_MID && vec_in && vec_out &&
+        in_dtype == p->dtype && n_slabs <= (int64_t)kPipeMaxSlabs && (int64_t)(work_bytes / sbytes) >= n_slabs && sbytes < ((size_t)1 << 31) &&
+        pass_bits[1] >= 7 && n_ch % CS == 0) {
+        const int K0 = pass_bits[0], K1 = pass_bits[1];
+        PipeArgs pa;
+        memset(&pa, 0, sizeof pa);
+        a.ch_first = 0; a.n_slab_groups = (uint32_t)n_slabs; a.macro_first = 0; a.slab_fastest = 0; a.swz_group = 0;
+        a.work_slab_stride = work_rows_total(N_eff) * U0(tc); a.work_row_stride = U0(tc);
+        a.work_slab_bytes = (uint32_t)sbytes;
+        a.n_macro = (uint32_t)(1u << (N_eff - K0 - log2_tiles(K0, tc)));
+        pa.p1 = a; pa.p1.b = 0; pa.p1.work_keep_st = 2; pa.p1.work_keep_ld = 1;
+        pa.p2 = a; pa.p2.b = K0; pa.p2.work_keep_st = 1; pa.p2.work_keep_ld = 1;
+        pa.p2.n_macro = (uint32_t)(1u << (N_eff - K1 - log2_tiles(K1, tc)));
+        pa.state = p->d_pipe;
+        pa.tiles = pa.p1.n_macro;
+        pa.n_slabs = (uint32_t)n_slabs;
+        // stream B starts one slab and a launch's worth of resident workgroups behind stream A: when a scatter tile takes its ticket,
+        // the last gather tile of its slab took its own at least that many tickets ago
+        const uint64_t nA = (uint64_t)pa.tiles * pa.n_slabs;
+        static const uint32_t env_delay = [] { const char *v = getenv("ZMLS_PIPE_DELAY"); return (v && *v) ? (uint32_t)strtoul(v, nullptr, 10) : 0u; }();   // tuning
+        const uint64_t want_delay = (uint64_t)pa.tiles + (p->pipe_delay ? p->pipe_delay : env_delay ? env_delay : 768u);
+        pa.delay = (uint32_t)std::min<uint64_t>(want_delay, nA);
+        if (pa.p1.n_macro == pa.p2.n_macro && nA * 2 <= 0x7FFFFFFFull) {
+            ZHIP(hipMemsetAsync(p->d_pipe, 0, (((size_t)4 + pa.n_slabs) * sizeof(uint32_t) + 15) & ~(size_t)15, st));
+            if (ev) ZHIP(hipEventRecord(ev[0], st));
+            ++p->last_launches[0];
+            rc = (p->dtype == ZMLS_F64 ? launch_pipeline_f64 : launch_pipeline_f32)(K0, K1, pa, st);
+            if (rc != ZMLS_E_UNSUPPORTED) {
+                if (rc) return rc;
+                if (ev) {
+                    float ms = 0.f;
+                    ZHIP(hipEventRecord(ev[1], st));
+                    ZHIP(hipEventSynchronize(ev[1]));
+                    ZHIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+                    pass_ms[0] += ms;
+                }
+                return ZMLS_OK;
+            }
+            --p->last_launches[0];
+            rc = ZMLS_OK;       // no kernel for this split: the launches below
+        }
+    }
     // Two lanes (tuning flag 4): consecutive chunks alternate between the caller's stream and the plan's second one, each
     // with half the chunk size, so that one chunk's launch tails run beside the other's bodies; forked and joined with
     // events, nothing of it is visible to the caller's stream order.

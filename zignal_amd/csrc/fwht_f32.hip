@@ -2,4 +2,5 @@
 #include "zmls_internal.h"
 #define ZT float
 #define ZLAUNCH launch_pass_f32
+#define ZPIPELINE launch_pipeline_f32
 #include "fwht_kernels.inc"

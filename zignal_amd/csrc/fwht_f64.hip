@@ -2,4 +2,5 @@
 #include "zmls_internal.h"
 #define ZT double
 #define ZLAUNCH launch_pass_f64
+#define ZPIPELINE launch_pipeline_f64
 #include "fwht_kernels.inc"

@@ -94,7 +94,8 @@ struct PassArgs {
     int slab_fastest;         // later passes: consecutive blocks are the slabs of one tile (else the tiles of one slab)
     void *work;               // row d of the transform of slab s at vector  s*work_slab_stride + work_row(d)*work_row_stride
     uint64_t work_slab_stride, work_row_stride;   // in 16-byte vectors: slab-major [slab][row][2^LU] or row-major [row][slab][2^LU]
-    int work_keep_ld, work_keep_st;   // 1: default cache policy for the intermediate's loads / stores (cache-resident schedule), 0: non-temporal
+    int work_keep_ld, work_keep_st;   // 1: default cache policy for the intermediate's loads / stores (cache-resident schedule), 0: non-temporal; stores 2: write-through (one-launch schedule)
+    uint32_t work_slab_bytes; // one-launch schedule: bytes of one slab of the workspace (< 2^31: the stores go through a buffer descriptor)
     uint32_t macro_first;     // first macro tile of this launch (row-range chunks of the cache-resident schedule)
     // gather-in
     const void *x;
@@ -166,6 +167,17 @@ size_t pc_slab_bytes(const zmls_plan *p);                // ... in slabs of this
 // pageable host memory <-> device memory, large copies in chunks through pinned bounce buffers on several streams (hostcopy.hip)
 int host_copy(int device, void *d_ptr, void *h_ptr, size_t bytes, bool to_device);
 
+// both passes of a two-pass order in one launch (fwht_kernels.inc::fwht_pipeline_kernel)
+struct PipeArgs {
+    PassArgs p1, p2;
+    uint32_t *state;            // [0] ticket counter, [1] time-out flag, [4 + s] gather tiles of slab s done; zeroed before the launch
+    uint32_t tiles;             // macro tiles per slab and pass
+    uint32_t n_slabs;
+    uint32_t delay;             // tiles by which stream B runs behind stream A (<= tiles * n_slabs)
+};
+constexpr uint32_t kPipeMaxSlabs = 65536;
+int launch_pipeline_f64(int K0, int K1, const PipeArgs &pa, hipStream_t st);
+int launch_pipeline_f32(int K0, int K1, const PipeArgs &pa, hipStream_t st);
 int launch_pass_f64(int cfg, int K, int inm, int outm, const PassArgs &a, hipStream_t st);
 int launch_pass_f32(int cfg, int K, int inm, int outm, const PassArgs &a, hipStream_t st);
 
@@ -231,5 +243,7 @@ struct zmls_plan {
     size_t resident_bytes;        // its chunk size (0: kResidentBytes)
     hipStream_t aux_stream;       // second lane of the cache-resident schedule and its fork / join events (created on demand)
     hipEvent_t ev_fork, ev_join;
-    int resident_flags;           // tuning: 4 = chunks alternate between two streams, 1 = pass 2 of three keeps its stores in the cache too, 2 = non-temporal loads of the resident intermediate
+    int resident_flags;           // tuning: 4 = chunks alternate between two streams, 1 = pass 2 of three keeps its stores in the cache too, 2 = non-temporal loads of the resident intermediate, 8 = both passes of a two-pass order in one launch
+    uint32_t *d_pipe;             // one-launch schedule: ticket counter, time-out flag and one counter per slab (4 + kPipeMaxSlabs words, made on demand)
+    uint32_t pipe_delay;          // ... tiles by which the scatter stream trails the gather stream beyond one slab (0: default)
 };
