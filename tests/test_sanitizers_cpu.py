@@ -39,6 +39,6 @@ def test_library_host_logic_under_asan_and_ubsan(tmp_path):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as pool:
         list(pool.map(lambda fo: subprocess.check_call([HIPCC] + flags + ["-x", "hip", "-c", fo[0], "-o", fo[1]], timeout=1500), zip(files, objs)))
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-fsanitize=address", "-fsanitize=undefined"] + objs + ["-o", exe], timeout=600)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined"] + objs + ["-o", exe], timeout=600)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=ENV)
     assert r.returncode == 0 and "host selftest ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
