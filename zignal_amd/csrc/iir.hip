@@ -47,11 +47,15 @@ constexpr int kIirLevels = 17;     // P[d] = A^(32 * 2^d), d = 0..16: runs (d < 
 constexpr int kIirGroup = 256;     // chunks per group of the second-level scan
 constexpr int kIirSerialChunks = 16;   // up to here one thread per channel walks the chunks
 constexpr int kIirPitch = kIirSub + 1;
+constexpr int kIirDotFrames = 512;   // frames of a frame-major chunk tile (256 / 16 runs of kIirSub): the dot-product form of the fused sweep
 constexpr size_t kIirSegmentBytes = 0;   // signal per segment of the time axis (launch_iir_s); 0 = one segment: segments of 64-192 MiB measured 14-28 % SLOWER (profiles/r03_iir_segments.txt)
 
 struct IirDev {
     double b[kIirMaxS + 1], a[kIirMaxS + 1];       // normalised: a[0] = 1
     double P[kIirLevels][kIirMaxS * kIirMaxS];     // row-major, row stride kIirMaxS
+    // zero-state end state of a 512-frame chunk as a weighted sum of its samples: E = sum_i W[i] x[i], W[i] = A^(511-i) beta,
+    // beta_k = b[k+1] - a[k+1] b[0] (the input vector of the transposed direct form II); [frame][state], state stride = the order S
+    double W16[kIirDotFrames * kIirMaxS];
 };
 
 namespace {
@@ -448,6 +452,77 @@ __global__ void __launch_bounds__(256, (S <= 5 ? 2 : 1)) iir_period_kernel(const
     double z[S];
 
     if constexpr (CC == 16) {
+        if (vec == 2 && interior) {
+            // The same tiles with the chunk's end state taken as a WEIGHTED SUM of its samples (IirDev::W16) instead of running the
+            // recurrence: the state after the chunk is linear in the chunk, E = sum_i A^(TT-1-i) beta x[i], so every thread multiplies
+            // the 16 vectors it has just loaded by their frames' weights, the 8 lanes of a wave that share a channel pair add up
+            // (three xor shuffles), and the four waves' partial sums wait in LDS until a batch of periods is full. No tile in LDS, no
+            // 32-step recurrence, no nine barriers per period: between two flushes the sweep is a plain stream of 16-byte loads.
+            // (Another order of the same additions as the recurrence: equal to rounding, 1e-16 of the state's size.)
+            typedef double D2 __attribute__((ext_vector_type(2)));
+            constexpr int NV = PER / 2;
+            constexpr int kPartAt = kIirDotFrames * kIirMaxS;                          // the partial sums' place behind the weights
+            constexpr int PB = (256 * kIirPitch - kPartAt) / (64 * S);                // periods per flush
+            static_assert(TT == kIirDotFrames && PB >= 1, "dot-product form: tile shape");
+            double *Wl = tile, *part = tile + kPartAt;
+            for (int i = tid; i < TT * S; i += 256) Wl[i] = f->W16[i];
+            __syncthreads();
+            const int fr = tid >> 3, cpi = tid & 7, cp = cpi * 2, wave = tid >> 6;
+            const int64_t vstep = 32 * rs;
+            D2 acc2[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) acc2[i] = (D2)0.0;
+            int slot = 0, r_first = 0;
+            // (the weights of a thread's 16 frames kept in registers - 64 of them at order 2 - spill; they are read from LDS per period)
+            // (issuing period r + 1's loads ahead of the lane sums of period r measured 15.9 against 12.4 ms for this sweep)
+            for (int r = 0; r < R; ++r) {
+                const double *q = (const double *)x + ((int64_t)r * L + j0 + fr) * rs + c0 + cp;
+                D2 v2[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i, q += vstep) v2[i] = __builtin_nontemporal_load((const D2 *)q);
+                if (r >= 1) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) acc2[i] += v2[i];       // period order, as numpy adds the rows (mls.py:298-306)
+                }
+                if (r + 1 == R) break;                                   // the last period rings into nothing that is kept
+                D2 p[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) p[k] = (D2)0.0;
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) p[k] += Wl[(fr + 32 * i) * S + k] * v2[i];
+#pragma unroll
+                for (int k = 0; k < S; ++k)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        double t = p[k][ch];
+                        t += __shfl_xor(t, 8, 64);
+                        t += __shfl_xor(t, 16, 64);
+                        t += __shfl_xor(t, 32, 64);
+                        if ((tid & 63) < 8) part[((slot * 4 + wave) * 8 + cpi) * (2 * S) + k * 2 + ch] = t;
+                    }
+                ++slot;
+                if (slot == PB || r + 2 == R) {
+                    __syncthreads();
+                    for (int o = tid; o < slot * 16 * S; o += 256) {
+                        const int pr = o / (16 * S), rem = o - pr * (16 * S), cc = rem / S, k = rem - cc * S;
+                        const int ci = cc >> 1, ch = cc & 1;
+                        double t = 0.0;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) t += part[((pr * 4 + w) * 8 + ci) * (2 * S) + k * 2 + ch];
+                        e[(((int64_t)(r_first + pr) * n_chunks + chunk) * n_ch + c0 + cc) * S + k] = t;
+                    }
+                    __syncthreads();
+                    r_first += slot;
+                    slot = 0;
+                }
+            }
+            double *o = sum + (j0 + fr) * srs + c0 + cp;
+#pragma unroll
+            for (int i = 0; i < NV; ++i, o += 32 * srs) __builtin_nontemporal_store(acc2[i], (D2 *)o);
+            return;
+        }
         if (vec && interior) {
             // interior tiles of aligned float64 frames: 16 loads of 16 bytes (two adjacent channels) in flight per lane.
             // Vector i of this thread is frame tid/8 + 32 i of the tile, channels 2 (tid%8) and 2 (tid%8) + 1: run i, offset tid/8.
@@ -592,6 +667,13 @@ __global__ void __launch_bounds__(64) iir_period_chain_kernel(const double *__re
     for (int k = 0; k < S; ++k) zi[c * S + k] = Z[k];
 }
 
+// ZMLS_IIR_DOT=0 (tuning): chunk end states of the fused sweep by the recurrence in LDS instead of the weighted sums
+static bool kDotSweep()
+{
+    static const bool on = [] { const char *v = getenv("ZMLS_IIR_DOT"); return !(v && *v == '0'); }();
+    return on;
+}
+
 template <int S, int CC>
 int launch_period_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t L, int64_t R, int64_t n_ch, int64_t rs, int64_t cs, double *d_e, double *d_E,
                     const double *d_phi, double *d_zi, double *d_sum, int64_t srs, int64_t scs, hipStream_t st)
@@ -602,7 +684,7 @@ int launch_period_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t L,
     if (blocks == 0 || blocks > 0x7FFFFFFFull || n_rc > 0x7FFFFFFFull * 64) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
     hipLaunchKernelGGL((iir_period_kernel<S, CC>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, L, (int)R, n_ch, rs, cs, (uint32_t)n_cgrp,
                        (int64_t)n_chunks, d_e, d_sum, srs, scs,
-                       (CC == 16 && cs == 1 && scs == 1 && rs % 2 == 0 && srs % 2 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_sum & 15) == 0) ? 1 : 0);
+                       (CC == 16 && cs == 1 && scs == 1 && rs % 2 == 0 && srs % 2 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_sum & 15) == 0) ? (kDotSweep() ? 2 : 1) : 0);
     hipLaunchKernelGGL(iir_period_end_kernel<S>, dim3((uint32_t)((n_rc + 63) / 64)), dim3(64), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch, (int64_t)n_rc,
                        (const double *)d_e, d_E);
     hipLaunchKernelGGL(iir_period_chain_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_phi, (int)R, n_ch, (const double *)d_E, d_zi);
@@ -751,6 +833,20 @@ int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, in
         for (int i = 0; i < S; ++i)
             for (int j = 0; j < S; ++j) h.P[d][i * kIirMaxS + j] = (double)Pw[i * S + j];
         mat_mul(S, Pw, Pw, Pw);
+    }
+    {
+        // weights of the dot-product form of the fused sweep: W[i] = A^(TT-1-i) beta, built backwards from the chunk's last frame
+        long double w[kIirMaxS] = {0}, t[kIirMaxS];
+        for (int k = 0; k < S; ++k) w[k] = (long double)h.b[k + 1] - (long double)h.a[k + 1] * (long double)h.b[0];
+        for (int i = kIirDotFrames - 1; i >= 0; --i) {
+            for (int k = 0; k < S; ++k) h.W16[i * S + k] = (double)w[k];
+            for (int r = 0; r < S; ++r) {
+                long double acc = 0;
+                for (int c = 0; c < S; ++c) acc += A_keep[r * S + c] * w[c];
+                t[r] = acc;
+            }
+            memcpy(w, t, sizeof(long double) * S);
+        }
     }
     zmls_iir *f = (zmls_iir *)calloc(1, sizeof(zmls_iir));
     if (!f) { set_error("out of host memory"); return ZMLS_E_ARG; }
