@@ -142,8 +142,13 @@ class Audio(object):
         rect = window in ('rectangular', 'boxcar', 'box', 'ones', 'rect')
         win = None if rect else scipy.signal.windows.get_window(window, Nx=self.nofsamples)   # not fftsize! (audio.py:690)
         mag = sp.magnitude_db_host(self.samples, win, normalise)
-        frq = np.fft.fftfreq(sp.fftsize, 1 / self.fs)[:int(sp.fftsize / 2)]
-        return frq, mag
+        # np.fft.fftfreq(fftsize, 1 / fs)[:int(fftsize / 2)] (audio.py:699-701) without its upper half: fftfreq is integers times
+        # 1.0 / (n * d), so these are the same doubles; kept with the shape's Spectrum, handed out as a copy
+        key = float(self.fs)
+        if getattr(sp, "_frq_fs", None) != key:
+            sp._frq = np.arange(int(sp.fftsize / 2)) * (1.0 / (sp.fftsize * (1 / self.fs)))
+            sp._frq_fs = key
+        return sp._frq.copy(), mag
 
     def plot_fft(self, plotname=None, window='hann', normalise=True, **kwargs):
         """Magnitude response plot with the reference's defaults (audio.py:649-676: hann window, one labelled line per

@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(256) spectrum_db_pairs_kernel(const double2 *_
 // 64 x 64 tile crosses LDS in between and both sides move whole 512-byte rows. (One element per lane with frames on the lanes
 // read 8 bytes out of every 512: the three kernels took 36 % of the call, profiles/r03_spectrum_kernel_stats.csv.)
 constexpr int kSpT = 64;            // frames (bins) and channels per tile
+constexpr size_t kSpectrumKeepBytes = (size_t)256 << 20;    // host-call staging kept with the object up to this size
 // (measured, profiles/r03_spectrum_own_fft.txt: 256 MiB best of 32 ... 512 MiB and all at once)
 constexpr size_t kSpectrumChunkBytes = (size_t)256 << 20;
 
@@ -197,6 +198,7 @@ struct zmls_spectrum {
     double2 *d_Y;           // Bluestein: (n_pairs, fftsize) spectra in natural order (power of two: d_work in the passes' order)
     double2 *d_table;       // Bluestein: spectrum of the chirp filter, 2^m points in the passes' order
     unsigned long long *d_peak;   // per-channel peak of the windowed samples (bit pattern of a double)
+    double *d_host[3];      // zmls_spectrum_host: response, spectrum and window on the device, kept between calls while small
 };
 
 using namespace zmls;
@@ -266,6 +268,8 @@ int zmls_spectrum_destroy(zmls_spectrum *s)
         if (s->d_Y) (void)hipFree(s->d_Y);
         if (s->d_table) (void)hipFree(s->d_table);
         if (s->d_peak) (void)hipFree(s->d_peak);
+        for (double *q : s->d_host)
+            if (q) (void)hipFree(q);
     }
     free(s);
     return ZMLS_OK;
@@ -345,21 +349,28 @@ int zmls_spectrum_host(zmls_spectrum *s, const double *h, const double *window, 
     if (!s || !h || !mag) { set_error("null argument"); return ZMLS_E_ARG; }
     ZDEVICE(s->device);
     int rc = ZMLS_OK;
-    double *d_h = nullptr, *d_w = nullptr, *d_m = nullptr;
-    const size_t hb = (size_t)s->n * s->n_ch * 8, mb = (size_t)s->n_bins * s->n_ch * 8;
-    hipError_t e = hipMalloc((void **)&d_h, hb);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_m, mb);
-    if (e == hipSuccess && window) e = hipMalloc((void **)&d_w, (size_t)s->n * 8);
-    if (e == hipSuccess && host_copy(s->device, d_h, (void *)h, hb, true) != ZMLS_OK) e = hipErrorUnknown;
-    if (e == hipSuccess && window && host_copy(s->device, d_w, (void *)window, (size_t)s->n * 8, true) != ZMLS_OK) e = hipErrorUnknown;
+    // staging for the host call: made on the first one and kept with the object (three hipMalloc / hipFree pairs per call cost more
+    // than the transform of a single response); held while small, per call beyond kSpectrumKeepBytes
+    const size_t hb = (size_t)s->n * s->n_ch * 8, mb = (size_t)s->n_bins * s->n_ch * 8, wb = (size_t)s->n * 8;
+    const bool keep = hb + mb + wb <= kSpectrumKeepBytes;
+    double *d_h = s->d_host[0], *d_m = s->d_host[1], *d_w = s->d_host[2];
+    hipError_t e = hipSuccess;
+    if (!d_h) e = hipMalloc((void **)&d_h, hb);
+    if (e == hipSuccess && !d_m) e = hipMalloc((void **)&d_m, mb);
+    if (e == hipSuccess && !d_w) e = hipMalloc((void **)&d_w, wb);
     if (e != hipSuccess) rc = hip_fail(e, "spectrum staging");
-    if (!rc) rc = zmls_spectrum_device(s, d_h, s->n_ch, 1, d_w, normalise, d_m, nullptr);
-    if (!rc) {
-        rc = host_copy(s->device, d_m, mag, mb, false);
+    if (keep && !rc) { s->d_host[0] = d_h; s->d_host[1] = d_m; s->d_host[2] = d_w; }
+    if (!rc) rc = host_copy(s->device, d_h, (void *)h, hb, true);
+    if (!rc && window) rc = host_copy(s->device, d_w, (void *)window, wb, true);
+    if (!rc) rc = zmls_spectrum_device(s, d_h, s->n_ch, 1, window ? d_w : nullptr, normalise, d_m, nullptr);
+    if (!rc) rc = host_copy(s->device, d_m, mag, mb, false);
+    if (!keep || rc) {
+        // (after an error nothing is kept either: the next call starts from scratch)
+        if (d_h) (void)hipFree(d_h);
+        if (d_m) (void)hipFree(d_m);
+        if (d_w) (void)hipFree(d_w);
+        s->d_host[0] = s->d_host[1] = s->d_host[2] = nullptr;
     }
-    if (d_h) (void)hipFree(d_h);
-    if (d_w) (void)hipFree(d_w);
-    if (d_m) (void)hipFree(d_m);
     return rc;
 }
 
