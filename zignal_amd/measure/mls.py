@@ -146,7 +146,8 @@ class _MLS_base(object):
 
     def xcorr_circular(self, other):
         """Circular cross-correlation of one period `other` ((L,) or (L,1)) with the sequence,
-        normalised by L -> (L, 1) float64 (mls.py:169-256)."""
+        normalised by L -> (L, 1) float64 (mls.py:169-256). Any other length is a ValueError, as in the reference, whose
+        `x1[:] = x1 + x2` (mls.py:229-239) cannot broadcast (n-1, 1) against (L-1, 1) unless n == L."""
         other = np.asarray(other)
         one = other.reshape(-1)
         if one.shape[0] != self.L:
