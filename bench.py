@@ -22,6 +22,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   configs      : (N=1, default workload) the other BASELINE.json configurations that fit one GPU, a few
                  steps each with their own roofline, parity against the oracle and CPU baseline
   order_sweep  : (with configs) N = 16..24 on the same 10.7 GB of capture each (2^(28-N) channels x 4 averaged periods)
+  next_rows    : (with configs) SURVEY §8(f) rows, device time per call: magnitude response, emphasis filter, fused de-emphasis
   period_mode  : (N>1) the same batch with the PERIODS striped over the GPUs instead of the channels:
                  partial period sums reduce-scattered with RCCL over xGMI (BASELINE config 3's
                  "RCCL reduce"); `value` stays the channel-sharded (collective-free) number.
@@ -429,6 +430,50 @@ def order_sweep(dev):
 
 
 # --------------------------------------------------------------------------------------------- the RCCL leg
+def next_rows(dev):
+    """the rows either side of the hot path, device time per call on synthetic data (parity: tests/test_gpu_iir.py,
+    test_gpu_spectrum.py, test_gpu_sources.py; tools/secondary_bench.py prints more shapes). Never part of `value`."""
+    from zignal_amd.device import IirFilter, Spectrum
+
+    def timed(fn, reps):
+        fn(); sync(dev)
+        t = Timer(dev)
+        t.start()
+        for _ in range(reps):
+            fn()
+        t.stop(); sync(dev)
+        return t.elapsed_ms() / reps
+
+    rows = {}
+    for N, C in ((20, 1), (20, 64)):
+        L = (1 << N) - 1
+        sp = Spectrum(L, C, device=dev)
+        h = DeviceBuffer(L * C * 8, dev); h.fill(0)
+        m = DeviceBuffer(sp.n_bins * C * 8, dev)
+        rows["spectrum_N%d_x%d_ms" % (N, C)] = timed(lambda: sp.magnitude_db_device(h.ptr, C, 1, None, False, m.ptr), 5)
+        sp.close(); h.free(); m.free()
+    N, C, R = 20, 512, 17
+    L = (1 << N) - 1
+    B, A = [1.0, -1.9, 0.9], [1.2, -1.8, 0.7]                    # a minimum-phase biquad and its inverse, like MLS's emphasis pair
+    f = IirFilter(A, B, device=dev)
+    x = DeviceBuffer(R * L * C * 8, dev); x.fill(0)
+    y = DeviceBuffer(2 * L * C * 8, dev)
+    f.reserve(2 * L, C)
+    rows["filter_2L_x512_ms"] = timed(lambda: f.filter_device(x.ptr, _lib.ZMLS_F64, 2 * L, C, C, 1, y.ptr, C, 1), 3)
+    y.free()
+    p = Plan(N, TAPS[N][0], device=dev)
+    p.reserve(C, staging=True)
+    hh = DeviceBuffer(L * C * 8, dev)
+    f.reserve_fused(p, R * L, C)
+    rows["deemphasis_fused_with_impulse_N20_x512_x17_ms"] = timed(lambda: p.impulse_filtered_device(f, x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, hh.ptr, C, 1), 3)
+    rows["impulse_same_capture_ms"] = timed(lambda: p.impulse_device(x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, hh.ptr, C, 1), 3)
+    x.free(); hh.free(); f.close(); p.close()
+    rows["what"] = ("device time per call, synthetic data: magnitude response (Audio.fft, own transform passes) of N=20 responses; the emphasis "
+                    "filter over 2 periods x 512 channels; MLS_simple.get_impulse's de-emphasis + impulse response in one call on 17 periods x "
+                    "512 channels, and the plain impulse response of the same (plainly allocated) capture beside it")
+    return rows
+
+
 def period_leg(args, world, rank, dev, rdzv, plan, dtype_code, es, C, R, result):
     """The same batch with the periods, not the channels, spread over the ranks (second mode): rank r
     holds periods r, r+world, ... of ALL world*C channels, adds them up, the partial sums are reduce-scattered with RCCL
@@ -747,6 +792,10 @@ def main():
             out["order_sweep"] = order_sweep(dev)
         except Exception as e:  # noqa: BLE001
             out["order_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            out["next_rows"] = next_rows(dev)
+        except Exception as e:  # noqa: BLE001
+            out["next_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
         bad = [c.get("workload", c["baseline_config"]) for c in extra if "error" in c
                or (c.get("parity_max_rel_err_vs_oracle") or 0) > TOL[c["dtype"]]
                or c["system_check_max_abs_err"] > noise_tolerance(c["averaged_periods"], (1 << c["order"]) - 1)]
