@@ -250,17 +250,31 @@ class MLS(_MLS_base, Audio):
         x2, code, n_rows, n_ch, rs, cs = Plan._as_capture(x)
         if n_rows % self.L:
             raise ValueError("number of frames %d is not a multiple of L=%d" % (n_rows, self.L))
-        d_x = DeviceBuffer(((n_rows - 1) * rs + (n_ch - 1) * cs + 1) * x2.itemsize, plan.device)
-        d_h = DeviceBuffer(self.L * plan.np_dtype().itemsize, plan.device)
+        # capture and response on the device: kept with the object between calls of one size while small (two hipMalloc / hipFree
+        # pairs cost more than the kernels of a one-channel call), as zmls_impulse_host keeps its own
+        nbytes = ((n_rows - 1) * rs + (n_ch - 1) * cs + 1) * x2.itemsize
+        kept = getattr(self, "_call_bufs", None)
+        if kept is not None and kept[0] != nbytes:
+            kept[1].free(); kept[2].free()
+            kept = self._call_bufs = None
+        if kept is None:
+            kept = (nbytes, DeviceBuffer(nbytes, plan.device), DeviceBuffer(self.L * plan.np_dtype().itemsize, plan.device))
+        d_x, d_h = kept[1], kept[2]
         try:
             _L.check(_L.lib().zmls_dev_upload(plan.device, d_x.ptr, x2.ctypes.data, d_x.nbytes))
             iir.reserve_fused(plan, n_rows, 1)
             plan.impulse_filtered_device(iir, d_x.ptr, code, n_rows, 1, rs, cs, d_h.ptr, 1, 1)
             sync(plan.device)
             imp = d_h.download((self.L, 1), plan.np_dtype).astype(np.float64, copy=False)
-        finally:
-            d_x.free()
-            d_h.free()
+        except BaseException:
+            d_x.free(); d_h.free()
+            self._call_bufs = None
+            raise
+        if nbytes <= (256 << 20):
+            self._call_bufs = kept
+        else:
+            d_x.free(); d_h.free()
+            self._call_bufs = None
         return Audio(fs=self.fs, initialdata=imp)
 
     def get_impulses_deemphasised(self, x):
