@@ -47,6 +47,7 @@ constexpr int kIirLevels = 17;     // P[d] = A^(32 * 2^d), d = 0..16: runs (d < 
 constexpr int kIirGroup = 256;     // chunks per group of the second-level scan
 constexpr int kIirSerialChunks = 16;   // up to here one thread per channel walks the chunks
 constexpr int kIirPitch = kIirSub + 1;
+constexpr size_t kIirHostKeepBytes = (size_t)256 << 20;   // zmls_iir_host keeps its device staging up to this size (in + out)
 constexpr int kIirDotFrames = 512;   // frames of a frame-major chunk tile (256 / 16 runs of kIirSub): the dot-product form of the fused sweep
 constexpr size_t kIirSegmentBytes = 0;   // signal per segment of the time axis (launch_iir_s); 0 = one segment: segments of 64-192 MiB measured 14-28 % SLOWER (profiles/r03_iir_segments.txt)
 
@@ -724,6 +725,8 @@ struct zmls_iir {
     double *d_e, *d_E, *d_zi, *d_sum, *d_phi;          // chunk end states of every period, period end states, sum of start states, period sums, A^L
     size_t e_elems, E_elems, zi_elems, sum_elems;
     int64_t phi_L;             // the period length d_phi was built for
+    void *d_host[2];           // zmls_iir_host: signal in / out on the device, kept between calls while small
+    size_t host_bytes[2];
 };
 
 using namespace zmls;
@@ -877,6 +880,8 @@ int zmls_iir_destroy(zmls_iir *f)
         if (f->d_zg) (void)hipFree(f->d_zg);
         if (f->d_sg) (void)hipFree(f->d_sg);
         if (f->d_carry) (void)hipFree(f->d_carry);
+        for (void *q : f->d_host)
+            if (q) (void)hipFree(q);
         double *fused[5] = {f->d_e, f->d_E, f->d_zi, f->d_sum, f->d_phi};
         for (double *q : fused)
             if (q) (void)hipFree(q);
@@ -1023,17 +1028,39 @@ int zmls_iir_host(zmls_iir *f, const void *x, int in_dtype, int64_t n_rows, int6
     ZDEVICE(f->device);                 // the staging buffers and the copies below belong to the filter's device
     const size_t in_span = (size_t)((n_rows - 1) * row_stride + (n_ch - 1) * ch_stride + 1) * is;
     const size_t out_bytes = (size_t)n_rows * n_ch * 8;
+    // staging on the device: kept with the filter between calls while small and large enough (grow-only), per call beyond that
+    // (two hipMalloc / hipFree pairs cost more than filtering a one-channel stimulus, as in zmls_impulse_host)
+    const bool keep = in_span + out_bytes <= kIirHostKeepBytes;
     void *d_x = nullptr;
     double *d_y = nullptr;
-    hipError_t e = hipMalloc(&d_x, in_span);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_y, out_bytes);
+    hipError_t e = hipSuccess;
+    if (keep) {
+        if (f->host_bytes[0] < in_span) {
+            if (f->d_host[0]) (void)hipFree(f->d_host[0]);
+            f->d_host[0] = nullptr; f->host_bytes[0] = 0;
+            e = hipMalloc(&f->d_host[0], in_span);
+            if (e == hipSuccess) f->host_bytes[0] = in_span;
+        }
+        if (e == hipSuccess && f->host_bytes[1] < out_bytes) {
+            if (f->d_host[1]) (void)hipFree(f->d_host[1]);
+            f->d_host[1] = nullptr; f->host_bytes[1] = 0;
+            e = hipMalloc(&f->d_host[1], out_bytes);
+            if (e == hipSuccess) f->host_bytes[1] = out_bytes;
+        }
+        d_x = f->d_host[0]; d_y = (double *)f->d_host[1];
+    } else {
+        e = hipMalloc(&d_x, in_span);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_y, out_bytes);
+    }
     if (e != hipSuccess) rc = hip_fail(e, "filter staging");
     if (!rc) rc = host_copy(f->device, d_x, (void *)x, in_span, true);
     // the result keeps the layout class of the input: (n_rows, n_ch) C-contiguous
     if (!rc) rc = zmls_iir_device(f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, d_y, n_ch, 1, nullptr);
     if (!rc) rc = host_copy(f->device, d_y, y, out_bytes, false);
-    if (d_x) (void)hipFree(d_x);
-    if (d_y) (void)hipFree(d_y);
+    if (!keep) {
+        if (d_x) (void)hipFree(d_x);
+        if (d_y) (void)hipFree(d_y);
+    }
     return rc;
 }
 
