@@ -153,6 +153,43 @@ __global__ void __launch_bounds__(256) spectrum_prepare_pairs_rows_kernel(const 
     }
 }
 
+// the same for even channel counts on 16-byte-aligned rows: a pair IS 16 adjacent bytes of a frame, so the response side moves
+// double2 as well (32 lanes x 16 bytes per row, eight rows per load instruction, all eight loads of a thread in flight; 8-byte
+// loads run at 0.5-0.7 of the 16-byte rate)
+__global__ void __launch_bounds__(256) spectrum_prepare_pairs_rows16_kernel(const double *__restrict__ h, int64_t n, int64_t n_ch, int64_t row_stride,
+                                                                            const double *__restrict__ window, int64_t n_pairs,
+                                                                            const unsigned long long *__restrict__ peak, double2 *__restrict__ stage)
+{
+    typedef double D2 __attribute__((ext_vector_type(2)));
+    __shared__ D2 tile[kSpT][kSpT / 2 + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pr = threadIdx.x & 31, r0 = threadIdx.x >> 5;            // pair of the tile, first of this thread's eight rows
+    const int64_t t0 = (int64_t)blockIdx.x * kSpT, c0 = (int64_t)blockIdx.y * kSpT;
+    const bool have = c0 + 2 * pr < n_ch;
+    D2 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t t = t0 + r0 + 8 * i;
+        v[i] = (have && t < n) ? __builtin_nontemporal_load((const D2 *)(h + t * row_stride + c0 + 2 * pr)) : (D2)0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t t = t0 + r0 + 8 * i;
+        tile[r0 + 8 * i][pr] = (window && t < n) ? v[i] * window[t] : v[i];
+    }
+    __syncthreads();
+    for (int pl = wv; pl < kSpT / 2; pl += 4) {
+        const int64_t p = c0 / 2 + pl, t = t0 + lane;
+        if (p < n_pairs && t < n) {
+            const D2 u = tile[lane][pl];
+            double2 o;
+            o.x = u[0];
+            o.y = ldexp(u[1], pair_shift(peak, p, n_ch));
+            stage[p * n + t] = o;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) spectrum_db_pairs_rows_kernel(const double2 *__restrict__ Y, int64_t F, int64_t n_bins, int64_t n_ch, int64_t n_pairs,
                                                                      double scale, const unsigned long long *__restrict__ peak, double *__restrict__ mag,
                                                                      const BinOrder order)
@@ -301,8 +338,12 @@ int zmls_spectrum_device(zmls_spectrum *s, const double *d_h, int64_t row_stride
         const int64_t rows_per_block = std::max<int64_t>(kSpT, (s->n + 4095) / 4096);
         hipLaunchKernelGGL(spectrum_peak_rows_kernel, dim3((uint32_t)((s->n + rows_per_block - 1) / rows_per_block), c_tiles), dim3(256), 0, st, d_h, s->n,
                            s->n_ch, row_stride, d_window, rows_per_block, s->d_peak);
-        hipLaunchKernelGGL(spectrum_prepare_pairs_rows_kernel, dim3((uint32_t)((s->n + kSpT - 1) / kSpT), c_tiles), dim3(256), 0, st, d_h, s->n, s->n_ch,
-                           row_stride, d_window, s->n_pairs, s->d_peak, s->d_stage);
+        if (s->n_ch % 2 == 0 && row_stride % 2 == 0 && ((uintptr_t)d_h & 15) == 0)
+            hipLaunchKernelGGL(spectrum_prepare_pairs_rows16_kernel, dim3((uint32_t)((s->n + kSpT - 1) / kSpT), c_tiles), dim3(256), 0, st, d_h, s->n, s->n_ch,
+                               row_stride, d_window, s->n_pairs, s->d_peak, s->d_stage);
+        else
+            hipLaunchKernelGGL(spectrum_prepare_pairs_rows_kernel, dim3((uint32_t)((s->n + kSpT - 1) / kSpT), c_tiles), dim3(256), 0, st, d_h, s->n, s->n_ch,
+                               row_stride, d_window, s->n_pairs, s->d_peak, s->d_stage);
     } else {
         hipLaunchKernelGGL(spectrum_peak_kernel, dim3(std::min<uint32_t>(grid(s->n), 1024u), (uint32_t)std::min<int64_t>(s->n_ch, 65535)), dim3(256), 0, st, d_h, s->n, s->n_ch,
                            row_stride, ch_stride, d_window, s->d_peak);
