@@ -129,6 +129,36 @@ __global__ void __launch_bounds__(256) spectrum_peak_rows_kernel(const double *_
     }
 }
 
+// ... with 16-byte loads (even channel counts on aligned rows): lane pr holds channels 2 pr and 2 pr + 1, eight row groups
+__global__ void __launch_bounds__(256) spectrum_peak_rows16_kernel(const double *__restrict__ h, int64_t n, int64_t n_ch, int64_t row_stride,
+                                                                   const double *__restrict__ window, int64_t rows_per_block,
+                                                                   unsigned long long *__restrict__ peak)
+{
+    typedef double D2 __attribute__((ext_vector_type(2)));
+    __shared__ double red[2][256];
+    const int pr = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int64_t c = (int64_t)blockIdx.y * kSpT + 2 * pr;
+    const int64_t t_begin = (int64_t)blockIdx.x * rows_per_block, t_end = t_begin + rows_per_block < n ? t_begin + rows_per_block : n;
+    double m0 = 0.0, m1 = 0.0;
+    if (c < n_ch) {
+        for (int64_t t = t_begin + rg; t < t_end; t += 8) {
+            const D2 v = __builtin_nontemporal_load((const D2 *)(h + t * row_stride + c));
+            const double w = window ? window[t] : 1.0, a = fabs(v[0] * w), b = fabs(v[1] * w);
+            if (a > m0 && a <= 1.7976931348623157e308) m0 = a;
+            if (b > m1 && b <= 1.7976931348623157e308) m1 = b;
+        }
+    }
+    red[0][threadIdx.x] = m0;
+    red[1][threadIdx.x] = m1;
+    __syncthreads();
+    if (rg == 0 && c < n_ch) {
+#pragma unroll
+        for (int g = 1; g < 8; ++g) { m0 = fmax(m0, red[0][g * 32 + pr]); m1 = fmax(m1, red[1][g * 32 + pr]); }
+        if (m0 > 0.0) atomicMax(peak + c, (unsigned long long)__double_as_longlong(m0));
+        if (m1 > 0.0) atomicMax(peak + c + 1, (unsigned long long)__double_as_longlong(m1));
+    }
+}
+
 __global__ void __launch_bounds__(256) spectrum_prepare_pairs_rows_kernel(const double *__restrict__ h, int64_t n, int64_t n_ch, int64_t row_stride,
                                                                           const double *__restrict__ window, int64_t n_pairs,
                                                                           const unsigned long long *__restrict__ peak, double2 *__restrict__ stage)
@@ -336,9 +366,14 @@ int zmls_spectrum_device(zmls_spectrum *s, const double *d_h, int64_t row_stride
     const bool rows = ch_stride == 1 && s->n_ch >= 8 && c_tiles <= 65535u;
     if (rows) {
         const int64_t rows_per_block = std::max<int64_t>(kSpT, (s->n + 4095) / 4096);
-        hipLaunchKernelGGL(spectrum_peak_rows_kernel, dim3((uint32_t)((s->n + rows_per_block - 1) / rows_per_block), c_tiles), dim3(256), 0, st, d_h, s->n,
-                           s->n_ch, row_stride, d_window, rows_per_block, s->d_peak);
-        if (s->n_ch % 2 == 0 && row_stride % 2 == 0 && ((uintptr_t)d_h & 15) == 0)
+        const bool wide = s->n_ch % 2 == 0 && row_stride % 2 == 0 && ((uintptr_t)d_h & 15) == 0;
+        if (wide)
+            hipLaunchKernelGGL(spectrum_peak_rows16_kernel, dim3((uint32_t)((s->n + rows_per_block - 1) / rows_per_block), c_tiles), dim3(256), 0, st, d_h, s->n,
+                               s->n_ch, row_stride, d_window, rows_per_block, s->d_peak);
+        else
+            hipLaunchKernelGGL(spectrum_peak_rows_kernel, dim3((uint32_t)((s->n + rows_per_block - 1) / rows_per_block), c_tiles), dim3(256), 0, st, d_h, s->n,
+                               s->n_ch, row_stride, d_window, rows_per_block, s->d_peak);
+        if (wide)
             hipLaunchKernelGGL(spectrum_prepare_pairs_rows16_kernel, dim3((uint32_t)((s->n + kSpT - 1) / kSpT), c_tiles), dim3(256), 0, st, d_h, s->n, s->n_ch,
                                row_stride, d_window, s->n_pairs, s->d_peak, s->d_stage);
         else
