@@ -81,6 +81,15 @@ __global__ void __launch_bounds__(256) spectrum_prepare_pairs_kernel(const doubl
     }
 }
 
+// 20 log10(g sqrt(re^2 + im^2)) as 10 log10(re^2 + im^2) + 20 log10(g): one logarithm and no hypot (its scaling and square root
+// are a third of this kernel's arithmetic); sums of squares near the ends of the double range take the long way
+__device__ __forceinline__ double db_of(double re, double im, double gain_db, double gain)
+{
+    const double ss = re * re + im * im;
+    if (ss > 1e-290 && ss < 1e290) return 10.0 * log10(ss) + gain_db;
+    return 20.0 * log10(hypot(re, im) * gain);
+}
+
 // packed mode: the two spectra of a pair from Z[k] and Z[F-k]
 __global__ void __launch_bounds__(256) spectrum_db_pairs_kernel(const double2 *__restrict__ Y, int64_t F, int64_t n_bins, int64_t n_ch, int64_t n_pairs,
                                                                 double scale, const unsigned long long *__restrict__ peak, double *__restrict__ mag,
@@ -91,9 +100,9 @@ __global__ void __launch_bounds__(256) spectrum_db_pairs_kernel(const double2 *_
         const int64_t p = idx / n_bins, k = idx - p * n_bins;
         const double2 a = Y[p * F + bin_at(order, k)], b = Y[p * F + bin_at(order, k ? F - k : 0)];
         // conj(b) = (b.x, -b.y):  X1 = (a + conj b) / 2,  |X2| = |a - conj b| / 2
-        const double m1 = 0.5 * hypot(a.x + b.x, a.y - b.y), m2 = 0.5 * hypot(a.x - b.x, a.y + b.y);
-        mag[k * n_ch + 2 * p] = 20.0 * log10(m1 * scale);
-        if (2 * p + 1 < n_ch) mag[k * n_ch + 2 * p + 1] = 20.0 * log10(ldexp(m2, -pair_shift(peak, p, n_ch)) * scale);
+        const double g1 = 0.5 * scale, g2 = ldexp(0.5 * scale, -pair_shift(peak, p, n_ch));
+        mag[k * n_ch + 2 * p] = db_of(a.x + b.x, a.y - b.y, 20.0 * log10(g1), g1);
+        if (2 * p + 1 < n_ch) mag[k * n_ch + 2 * p + 1] = db_of(a.x - b.x, a.y + b.y, 20.0 * log10(g2), g2);
     }
 }
 
@@ -225,15 +234,23 @@ __global__ void __launch_bounds__(256) spectrum_db_pairs_rows_kernel(const doubl
                                                                      const BinOrder order)
 {
     __shared__ double tile[kSpT][kSpT + 1];
+    __shared__ double gain[kSpT], gain_db[kSpT];        // per channel of the tile: 1/2 x scale x the undone level shift, and its dB
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t k0 = (int64_t)blockIdx.x * kSpT, c0 = (int64_t)blockIdx.y * kSpT;
+    if (threadIdx.x < kSpT) {
+        const int64_t c = c0 + threadIdx.x;
+        const double g = (c & 1) && c / 2 < n_pairs ? ldexp(0.5 * scale, -pair_shift(peak, c / 2, n_ch)) : 0.5 * scale;
+        gain[threadIdx.x] = g;
+        gain_db[threadIdx.x] = 20.0 * log10(g);
+    }
+    __syncthreads();
     for (int pl = wv; pl < kSpT / 2; pl += 4) {
         const int64_t p = c0 / 2 + pl, k = k0 + lane;
         double m1 = 0.0, m2 = 0.0;
         if (p < n_pairs && k < n_bins) {
             const double2 a = Y[p * F + bin_at(order, k)], b = Y[p * F + bin_at(order, k ? F - k : 0)];
-            m1 = 0.5 * hypot(a.x + b.x, a.y - b.y);
-            m2 = ldexp(0.5 * hypot(a.x - b.x, a.y + b.y), -pair_shift(peak, p, n_ch));
+            m1 = db_of(a.x + b.x, a.y - b.y, gain_db[2 * pl], gain[2 * pl]);
+            m2 = db_of(a.x - b.x, a.y + b.y, gain_db[2 * pl + 1], gain[2 * pl + 1]);
         }
         tile[lane][2 * pl] = m1;
         tile[lane][2 * pl + 1] = m2;
@@ -241,7 +258,7 @@ __global__ void __launch_bounds__(256) spectrum_db_pairs_rows_kernel(const doubl
     __syncthreads();
     for (int r = wv; r < kSpT; r += 4) {
         const int64_t k = k0 + r, c = c0 + lane;
-        if (k < n_bins && c < n_ch) mag[k * n_ch + c] = 20.0 * log10(tile[r][lane] * scale);
+        if (k < n_bins && c < n_ch) mag[k * n_ch + c] = tile[r][lane];
     }
 }
 
