@@ -96,6 +96,16 @@ int zmls_plan_force_pseudo_channels(zmls_plan *p, int mode);
  * No reference counterpart. */
 int zmls_iir_set_segment(zmls_iir *f, size_t bytes);
 
+/* Tests / tuning: which form zmls_impulse_filtered_device takes (csrc/iir.hip). 0: one sweep over the capture in time order
+ * (period sums + filter states), then the filter over the sums, then the transform. 1: the transform on the unfiltered capture,
+ * then the filter over the responses (circular, plus a rank-S term for the filter's state at the period boundaries, which comes
+ * from the last chunks of every period) - wherever it can run at all: float64 plans, filters whose memory fits a period.
+ * -1 (default): form 1 when the filter's memory is at most a quarter of a period, else form 0. Both are regroupings of the same
+ * linear map (mls.py:401-414: apply_deemphasis, then get_impulse): results agree to rounding. zmls_iir_last_fused_form: the form
+ * the most recent call took (0 / 1; -1 for a null filter). No reference counterpart. */
+int zmls_iir_set_fused_form(zmls_iir *f, int form);
+int zmls_iir_last_fused_form(const zmls_iir *f);
+
 /* Profiling: how many kernels the most recent impulse call on this plan launched, by kind - out[0] first (gather) pass, out[1]
  * middle passes, out[2] last (scatter) pass. The cache-resident schedule runs a step as many chunk launches; a profile's
  * per-launch counters times these counts are the step's (tools/summarize_profile.py). No reference counterpart. */

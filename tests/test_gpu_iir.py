@@ -8,7 +8,7 @@ import scipy.signal
 
 from gpu_common import rel_err
 from zignal_amd import _lib
-from zignal_amd.device import DeviceBuffer, IirFilter, sync
+from zignal_amd.device import DeviceBuffer, IirFilter, Plan, sync
 from zignal_amd.filters.biquads import RBJ
 from zignal_amd.measure.mls import MLS, TAPS, MLS_simple
 
@@ -225,6 +225,92 @@ def test_fused_path_equals_the_two_device_steps_at_n20():
         d.free()
     f.close()
     f2.close()
+
+
+def _fused_form(plan, iir, x, form, stacked_in=False, stacked_out=False):
+    """zmls_impulse_filtered_device in one of its two forms on capture x (frames, channels); either side frames x channels
+    or a stack of single-channel arrays. Returns the responses (L, channels) and the form the call took."""
+    n_rows, C = x.shape
+    src = np.ascontiguousarray(x.T) if stacked_in else x
+    d_x = DeviceBuffer(src.nbytes).upload(src)
+    d_h = DeviceBuffer(plan.L * C * 8)
+    d_h.fill(0xFF)
+    iir.reserve_fused(plan, n_rows, C)
+    iir.set_fused_form(form)
+    rs, cs = (1, n_rows) if stacked_in else (C, 1)
+    ors, ocs = (1, plan.L) if stacked_out else (C, 1)
+    plan.impulse_filtered_device(iir, d_x.ptr, _lib.dtype_code(src.dtype), n_rows, C, rs, cs, d_h.ptr, ors, ocs)
+    sync(0)
+    took = iir.last_fused_form()
+    iir.set_fused_form(-1)
+    h = d_h.download((C, plan.L) if stacked_out else (plan.L, C), np.float64)
+    d_x.free()
+    d_h.free()
+    return (h.T if stacked_out else h), took
+
+
+@pytest.mark.parametrize("N,C,R,order,stacked_in,stacked_out", [(12, 7, 5, 4, False, False), (13, 16, 4, 2, False, False), (14, 5, 3, 3, False, False),
+                                                               (14, 1, 3, 2, True, True), (15, 3, 2, 1, True, False), (16, 32, 17, 2, False, False),
+                                                               (16, 4, 3, 8, False, True), (17, 4, 2, 5, True, True), (18, 2, 3, 2, False, False)])
+def test_post_filter_form_of_the_fused_call(N, C, R, order, stacked_in, stacked_out):
+    """round 3: filter and transform commute up to a rank-S term (csrc/iir.hip, impulse_filtered_post), so the capture takes the
+    ordinary gather pass and the filter runs over the responses. Forced (form 1) it runs wherever the filter's memory fits a
+    period; against the sweep form (form 0) on the same buffers and against lfilter-then-oracle (mls.py:401-414)."""
+    from gpu_common import plan
+    taps = TAPS[N][0]
+    p = plan(N, taps)
+    rng = np.random.default_rng(2000 * N + C)
+    b, a = stable_filter(order, rng)
+    f = IirFilter(b, a, device=0)
+    x = rng.standard_normal((R * p.L, C))
+    sweep, took0 = _fused_form(p, f, x, 0, stacked_in, stacked_out)
+    post, took1 = _fused_form(p, f, x, 1, stacked_in, stacked_out)
+    assert (took0, took1) == (0, 1)
+    assert rel_err(post, sweep) <= 1e-13
+    if N <= 16:
+        assert rel_err(post, _reference_chain(N, taps, b, a, x)) <= TOL
+    # again on the same filter and plan (the tail and state arrays are reused), with a shorter capture
+    if R > 2:
+        x2 = x[:2 * p.L]
+        again, took = _fused_form(p, f, x2, 1, stacked_in, stacked_out)
+        ref2, _ = _fused_form(p, f, x2, 0, stacked_in, stacked_out)
+        assert took == 1 and rel_err(again, ref2) <= 1e-13
+    f.close()
+
+
+def test_post_filter_form_choice_and_raw_pcm_scale():
+    """auto: the post-filter form when the filter's memory is a small part of a period (N=16: 65535 frames against ~8000 for the
+    reference's shelving filter), the sweep form at short orders and for float32 plans; int16 captures with the 2^-15 scale
+    folded into the plan (zmls_plan_set_input_scale_log2) come out scaled in both forms."""
+    from gpu_common import plan
+    b, a = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=48000).get_coefficients()
+    f = IirFilter(a, b, device=0)
+    rng = np.random.default_rng(31)
+    for N, want_form in ((16, 1), (11, 0)):
+        p = plan(N, TAPS[N][0])
+        x = rng.standard_normal((3 * p.L, 4))
+        got, took = _fused_form(p, f, x, -1)
+        assert took == want_form
+        assert rel_err(got, _reference_chain(N, TAPS[N][0], a, b, x)) <= TOL
+    p32 = plan(16, TAPS[16][0], "f32")
+    f.reserve_fused(p32, 3 * p32.L, 4)
+    d_x, d_h = DeviceBuffer(3 * p32.L * 4 * 8), DeviceBuffer(p32.L * 4 * 4)
+    d_x.fill(0)
+    p32.impulse_filtered_device(f, d_x.ptr, _lib.ZMLS_F64, 3 * p32.L, 4, 4, 1, d_h.ptr, 4, 1)
+    sync(0)
+    assert f.last_fused_form() == 0
+    d_x.free(); d_h.free()
+    # raw PCM
+    N = 16
+    p = Plan(N, TAPS[N][0], device=0)
+    xi = (rng.standard_normal((3 * p.L, 6)) * 3000).astype(np.int16)
+    p.set_input_scale_log2(15)
+    want = _reference_chain(N, TAPS[N][0], a, b, xi.astype(np.float64) / 32768.0)
+    for form in (0, 1):
+        got, took = _fused_form(p, f, xi, form)
+        assert took == form and rel_err(got, want) <= TOL, form
+    p.close()
+    f.close()
 
 
 def test_mls_get_impulses_deemphasised_many_channels():

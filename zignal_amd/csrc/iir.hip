@@ -97,11 +97,13 @@ __device__ __forceinline__ double df2t_step(const IirDev *__restrict__ f, double
 
 // CC = channels per chunk tile: 1 for time-contiguous signals (8192 frames x 1 channel), 16 for frame-major ones
 // (512 frames x 16 channels); either way a tile is 8192 samples and a thread owns 32 consecutive frames of one channel.
-template <int S, int CC, bool FINAL>
+// FINAL: 0 first sweep (chunk end states), 1 second sweep (outputs), 2 second sweep with the rank-S term of the post-filter form
+template <int S, int CC, int FINAL>
 __global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict__ f, const void *__restrict__ x, int in_dtype, int64_t n_rows,
                                                         int64_t n_ch, int64_t rs, int64_t cs, uint32_t n_cgrp, double *__restrict__ zc,
                                                         const double *__restrict__ sin, double *__restrict__ y, int64_t ors, int64_t ocs,
-                                                        int keep /* first sweep of a segment: the second sweep wants these lines in the Infinity Cache */)
+                                                        int keep /* first sweep of a segment: the second sweep wants these lines in the Infinity Cache */,
+                                                        const double *__restrict__ psi, const double *__restrict__ zeta /* FINAL: y[t][c] += sum_k zeta[c][k] psi[t][k], or null */)
 {
     constexpr int NB = 256 / CC;
     constexpr int LOGNB = (CC == 1) ? 8 : 4;
@@ -109,6 +111,8 @@ __global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict
     static_assert(CC == 1 || CC == 16, "tile shapes built");
     __shared__ double tile[256 * kIirPitch];
     __shared__ double sc[256 * S];
+    // frame-major tiles of the final sweep keep the tile's rows of psi here (TT x S, one coalesced read; every row is used by 16 channels)
+    __shared__ double psl[(FINAL == 2 && CC == 16) ? TT * S : 1];
     const int tid = threadIdx.x;
     // frame-major tiles: the channel groups of one chunk are pieces of the same rows; renumbered so that they run on one XCD,
     // next to each other in time (workgroups are dealt to the 8 XCDs in turn)
@@ -117,6 +121,13 @@ __global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict
     const int64_t t0 = chunk * TT, c0 = (int64_t)(bid % n_cgrp) * CC;
 
     constexpr int PER = TT * CC / 256;             // elements per thread in the coalesced load / store sweeps (32)
+    if constexpr (FINAL == 2 && CC == 16) {
+        {
+            const int64_t have = (n_rows - t0 < TT ? n_rows - t0 : TT) * S;      // psi holds n_rows rows
+#pragma unroll
+            for (int i = 0; i < TT * S / 256; ++i) psl[tid + i * 256] = (tid + i * 256 < have) ? psi[t0 * S + tid + i * 256] : 0.0;
+        }
+    }
     if (in_dtype == ZMLS_F64 && t0 + TT <= n_rows && c0 + CC <= n_ch) {
         // interior tile of float64 data: all loads of a thread issued back to back (the kernel is bound by memory
         // latency otherwise: two workgroups per CU and one 8-byte load in flight per lane do not fill the HBM pipe)
@@ -197,10 +208,23 @@ __global__ void __launch_bounds__(256) iir_chunk_kernel(const IirDev *__restrict
 #pragma unroll 4
         for (int i = 0; i < kIirSub; ++i) tile[tid * kIirPitch + i] = df2t_step<S>(f, tile[tid * kIirPitch + i], z);
         __syncthreads();
+        // the post-filter form of the fused path (impulse_filtered_post) adds a rank-S term on the way out: the thread's channel in
+        // the store sweep is fixed (256 is a multiple of CC), so its S coefficients sit in registers and psi's rows are shared reads
+        double zt[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) zt[k] = (FINAL == 2 && c < n_ch) ? zeta[c * S + k] : 0.0;
         for (int e = tid; e < TT * CC; e += 256) {
             const int tt = e / CC, cc = e % CC;
             const int64_t t = t0 + tt, ch = c0 + cc;
-            if (t < n_rows && ch < n_ch) __builtin_nontemporal_store(tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)], y + t * ors + ch * ocs);
+            if (t < n_rows && ch < n_ch) {
+                double v = tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)];
+                if constexpr (FINAL == 2) {
+                    const double *ps = (CC == 16) ? psl + tt * S : psi + t * S;
+#pragma unroll
+                    for (int k = 0; k < S; ++k) v = __builtin_fma(zt[k], ps[k], v);
+                }
+                __builtin_nontemporal_store(v, y + t * ors + ch * ocs);
+            }
         }
     }
 }
@@ -325,7 +349,7 @@ __global__ void __launch_bounds__(64) iir_carry_kernel(const IirDev *__restrict_
 template <int S, int CC>
 int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs, double *d_zc, double *d_sin,
                  double *d_zg, double *d_sg, double *d_y, int64_t ors, int64_t ocs, const double *d_zi, double *d_carry, size_t segment_bytes,
-                 hipStream_t st)
+                 hipStream_t st, const double *d_psi = nullptr, const double *d_zeta = nullptr)
 {
     constexpr int NB = 256 / CC, TT = NB * kIirSub, LOGNB = (CC == 1) ? 8 : 4;
     const uint64_t n_cgrp = (uint64_t)((n_ch + CC - 1) / CC);
@@ -356,8 +380,9 @@ int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_row
         const bool more = r0 + rows < n_rows;
         const uint64_t n_chunks = (uint64_t)((rows + TT - 1) / TT);
         const uint64_t blocks = n_cgrp * n_chunks;
-        hipLaunchKernelGGL((iir_chunk_kernel<S, CC, false>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, x_seg, in_dtype, rows, n_ch, rs, cs,
-                           (uint32_t)n_cgrp, d_zc, (const double *)nullptr, (double *)nullptr, ors, ocs, keep_first);
+        hipLaunchKernelGGL((iir_chunk_kernel<S, CC, 0>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, x_seg, in_dtype, rows, n_ch, rs, cs,
+                           (uint32_t)n_cgrp, d_zc, (const double *)nullptr, (double *)nullptr, ors, ocs, keep_first, (const double *)nullptr,
+                           (const double *)nullptr);
         if (n_chunks <= (uint64_t)kIirSerialChunks) {
             hipLaunchKernelGGL(iir_combine_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
                                (const double *)d_zc, d_sin, zi_seg);
@@ -380,8 +405,12 @@ int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_row
         if (more)
             hipLaunchKernelGGL(iir_carry_kernel<S>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, d_f, LOGNB, (int64_t)n_chunks, n_ch,
                                (const double *)d_zc, (const double *)d_sin, d_carry);
-        hipLaunchKernelGGL((iir_chunk_kernel<S, CC, true>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, x_seg, in_dtype, rows, n_ch, rs, cs,
-                           (uint32_t)n_cgrp, (double *)nullptr, (const double *)d_sin, y_seg, ors, ocs, 0);
+        if (d_psi)
+            hipLaunchKernelGGL((iir_chunk_kernel<S, CC, 2>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, x_seg, in_dtype, rows, n_ch, rs, cs,
+                               (uint32_t)n_cgrp, (double *)nullptr, (const double *)d_sin, y_seg, ors, ocs, 0, d_psi + r0 * S, d_zeta);
+        else
+            hipLaunchKernelGGL((iir_chunk_kernel<S, CC, 1>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, x_seg, in_dtype, rows, n_ch, rs, cs,
+                               (uint32_t)n_cgrp, (double *)nullptr, (const double *)d_sin, y_seg, ors, ocs, 0, (const double *)nullptr, (const double *)nullptr);
     }
     ZHIP(hipGetLastError());
     return ZMLS_OK;
@@ -390,13 +419,14 @@ int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_row
 template <int S>
 int launch_iir_cc(bool time_contiguous, const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs,
                   double *d_zc, double *d_sin, double *d_zg, double *d_sg, double *d_y, int64_t ors, int64_t ocs, const double *d_zi, double *d_carry,
-                  size_t segment_bytes, hipStream_t st)
+                  size_t segment_bytes, hipStream_t st, const double *d_psi = nullptr, const double *d_zeta = nullptr)
 {
     // stacked single-channel signals (time-contiguous, several channels) are not cut: a segment of all channels is no contiguous
     // piece of memory there and the channels are far apart anyway
     if (time_contiguous) return launch_iir_s<S, 1>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, d_zi, d_carry,
-                                                   n_ch == 1 ? segment_bytes : 0, st);
-    return launch_iir_s<S, 16>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, d_zi, d_carry, segment_bytes, st);
+                                                   n_ch == 1 ? segment_bytes : 0, st, d_psi, d_zeta);
+    return launch_iir_s<S, 16>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, d_zi, d_carry, segment_bytes, st, d_psi,
+                               d_zeta);
 }
 
 // ---- the fused path: one sweep over the capture (period sums + chunk end states), then two small kernels
@@ -668,6 +698,102 @@ __global__ void __launch_bounds__(64) iir_period_chain_kernel(const double *__re
     for (int k = 0; k < S; ++k) zi[c * S + k] = Z[k];
 }
 
+// ---- the post-filter form of the fused path (impulse_filtered_post below): only the END of every period is read in time order
+// zero-state end state of tail chunk q (of nt, aligned to the period's end like iir_period_kernel's) of period r; r = 0..R-1.
+template <int S, int CC>
+__global__ void __launch_bounds__(256) iir_tail_kernel(const IirDev *__restrict__ f, const void *__restrict__ x, int in_dtype, int64_t L, int64_t n_ch,
+                                                       int64_t rs, int64_t cs, uint32_t n_cgrp, int nt, double *__restrict__ e)
+{
+    constexpr int NB = 256 / CC;
+    constexpr int TT = NB * kIirSub;
+    constexpr int PER = TT * CC / 256;
+    __shared__ double tile[256 * kIirPitch];
+    __shared__ double sc[256 * S];
+    const int tid = threadIdx.x;
+    const uint32_t cg = blockIdx.x % n_cgrp, rq = blockIdx.x / n_cgrp;
+    const int q = (int)(rq % (uint32_t)nt);
+    const int64_t r = rq / (uint32_t)nt;
+    const int64_t j0 = L - (int64_t)(nt - q) * TT, c0 = (int64_t)cg * CC;
+    double v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int el = tid + i * 256, tt = el / CC, cc = el % CC;
+        const int64_t j = j0 + tt, ch = c0 + cc;
+        v[i] = (j >= 0 && ch < n_ch) ? iir_load(x, (r * L + j) * rs + ch * cs, in_dtype) : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int el = tid + i * 256, tt = el / CC, cc = el % CC;
+        tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)] = v[i];
+    }
+    __syncthreads();
+    double z[S];
+    chunk_end_state<S, CC>(f, tile, sc, tid, z);
+    const int64_t c = c0 + tid % CC;
+    if (tid / CC == NB - 1 && c < n_ch) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) e[((r * nt + q) * n_ch + c) * S + k] = z[k];
+    }
+}
+
+// One thread per channel, from the period end states E[0..R-1] of the capture and E[R] of the unfiltered response:
+//   z_0 = 0, z_{r+1} = A^L z_r + E_r;  Zm = mean_{r=1..R-1} z_r (the filter's state at the start of the averaged periods),
+//   Em = mean_{r=1..R-1} E_r (the zero-state end state of the averaged period, by linearity),
+//   zeta = scale (Zm - (I - A^L)^-1 Em)   what the true start state has over the periodic steady state of the averaged period,
+//   zi   = (I - A^L)^-1 E_h               the start state that makes the filter over the response circular.
+template <int S>
+__global__ void __launch_bounds__(64) iir_post_state_kernel(const double *__restrict__ phi /* A^L */, const double *__restrict__ minv /* (I - A^L)^-1 */,
+                                                            int R, int64_t n_ch, const double *__restrict__ E, double scale,
+                                                            double *__restrict__ zeta, double *__restrict__ zi)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ch) return;
+    double z[S], Z[S], Es[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) z[k] = Z[k] = Es[k] = 0.0;
+    for (int r = 0; r < R; ++r) {
+        double t[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) t[k] = E[((int64_t)r * n_ch + c) * S + k];
+        if (r >= 1) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) { Z[k] += z[k]; Es[k] += t[k]; }
+        }
+        matvec_acc<S>(phi, z, t);
+#pragma unroll
+        for (int k = 0; k < S; ++k) z[k] = t[k];
+    }
+    const double inv = 1.0 / (double)(R - 1);
+    double em[S], zs[S], eh[S], z0[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) { em[k] = Es[k] * inv; zs[k] = 0.0; z0[k] = 0.0; eh[k] = E[((int64_t)R * n_ch + c) * S + k]; }
+    matvec_acc<S>(minv, em, zs);
+    matvec_acc<S>(minv, eh, z0);
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        zeta[c * S + k] = scale * (Z[k] * inv - zs[k]);
+        zi[c * S + k] = z0[k];
+    }
+}
+
+template <int S>
+int launch_tail_s(bool tc, const IirDev *d_f, const void *d_x, int in_dtype, int64_t L, int64_t R, int64_t n_ch, int64_t rs, int64_t cs, int nt, double *d_e,
+                  double *d_E, hipStream_t st)
+{
+    const int CC = tc ? 1 : 16;
+    const uint64_t n_cgrp = (uint64_t)((n_ch + CC - 1) / CC);
+    const uint64_t blocks = n_cgrp * (uint64_t)nt * (uint64_t)R, n_rc = (uint64_t)R * (uint64_t)n_ch;
+    if (blocks == 0 || blocks > 0x7FFFFFFFull || n_rc > 0x7FFFFFFFull * 64) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
+    if (tc)
+        hipLaunchKernelGGL((iir_tail_kernel<S, 1>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, L, n_ch, rs, cs, (uint32_t)n_cgrp, nt, d_e);
+    else
+        hipLaunchKernelGGL((iir_tail_kernel<S, 16>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, L, n_ch, rs, cs, (uint32_t)n_cgrp, nt, d_e);
+    hipLaunchKernelGGL(iir_period_end_kernel<S>, dim3((uint32_t)((n_rc + 63) / 64)), dim3(64), 0, st, d_f, tc ? 8 : 4, (int64_t)nt, n_ch, (int64_t)n_rc,
+                       (const double *)d_e, d_E);
+    ZHIP(hipGetLastError());
+    return ZMLS_OK;
+}
+
 // ZMLS_IIR_DOT=0 (tuning): chunk end states of the fused sweep by the recurrence in LDS instead of the weighted sums
 static bool kDotSweep()
 {
@@ -727,6 +853,14 @@ struct zmls_iir {
     int64_t phi_L;             // the period length d_phi was built for
     void *d_host[2];           // zmls_iir_host: signal in / out on the device, kept between calls while small
     size_t host_bytes[2];
+    // the post-filter form of the fused path (impulse_filtered_post)
+    int post_nt[2];            // chunks at the end of a period that hold all of its end state: [0] frame-major tiles (512 frames), [1] time-contiguous (8192); 0: the filter rings too long
+    int post_form;             // -1: the post-filter form where it applies, 0: never, 1: wherever it can run at all (tests)
+    int last_form;             // which form the most recent zmls_impulse_filtered_device call took: 0 sweep, 1 post-filter
+    double *d_zeta, *d_minv, *d_psi;   // per-channel coefficients of the rank-S term, (I - A^L)^-1, responses to the S zero-input basis sequences (L x S)
+    size_t zeta_elems, psi_elems;
+    int64_t psi_L;             // what d_psi was built for: period, register
+    uint32_t psi_G;
 };
 
 using namespace zmls;
@@ -806,6 +940,62 @@ int zmls::filtered_period_sums(zmls_plan *p, zmls_iir *f, const void *d_x, int i
     return ZMLS_OK;
 }
 
+namespace zmls {
+namespace {
+// smallest k with |(A^TT)^k| <= 1e-22 in every entry: samples more than k chunks before a period's end leave nothing of
+// themselves in its end state (0: more than 4096 chunks, the post-filter form is not for this filter)
+int tail_chunks(int S, const long double *M)
+{
+    long double Mk[kIirMaxS * kIirMaxS];
+    memcpy(Mk, M, sizeof Mk);
+    for (int k = 1; k <= 4096; ++k) {
+        long double mx = 0;
+        for (int i = 0; i < S * S; ++i) {
+            if (!(Mk[i] == Mk[i])) return 0;
+            mx = std::max(mx, fabsl(Mk[i]));
+        }
+        if (mx <= 1e-22L) return k;
+        mat_mul(S, Mk, M, Mk);
+    }
+    return 0;
+}
+
+// X <- X^-1 (S x S, long double, Gauss-Jordan with partial pivoting); false: singular
+bool mat_inv(int S, long double *X)
+{
+    long double W[kIirMaxS][2 * kIirMaxS];
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) { W[i][j] = X[i * S + j]; W[i][S + j] = i == j ? 1.0L : 0.0L; }
+    for (int c = 0; c < S; ++c) {
+        int piv = c;
+        for (int i = c + 1; i < S; ++i)
+            if (fabsl(W[i][c]) > fabsl(W[piv][c])) piv = i;
+        if (!(fabsl(W[piv][c]) > 1e-12L)) return false;
+        if (piv != c)
+            for (int j = 0; j < 2 * S; ++j) std::swap(W[piv][j], W[c][j]);
+        const long double d = 1.0L / W[c][c];
+        for (int j = 0; j < 2 * S; ++j) W[c][j] *= d;
+        for (int i = 0; i < S; ++i) {
+            if (i == c) continue;
+            const long double m = W[i][c];
+            if (m == 0.0L) continue;
+            for (int j = 0; j < 2 * S; ++j) W[i][j] -= m * W[c][j];
+        }
+    }
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) X[i * S + j] = W[i][S + j];
+    return true;
+}
+
+// ZMLS_FUSED_POST=0 (tuning): the fused call always sweeps the capture in time order
+bool kPostForm()
+{
+    static const bool on = [] { const char *v = getenv("ZMLS_FUSED_POST"); return !(v && *v == '0'); }();
+    return on;
+}
+} // namespace
+} // namespace zmls
+
 extern "C" {
 
 int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, int na, int device)
@@ -832,9 +1022,12 @@ int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, in
     long double A_keep[kIirMaxS * kIirMaxS];
     memcpy(A_keep, A, sizeof A_keep);
     for (int k = 0; k < 5; ++k) mat_mul(S, Pw, Pw, Pw);      // A^32
+    int post_nt[2] = {0, 0};
     for (int d = 0; d < kIirLevels; ++d) {
         for (int i = 0; i < S; ++i)
             for (int j = 0; j < S; ++j) h.P[d][i * kIirMaxS + j] = (double)Pw[i * S + j];
+        if (d == 4) post_nt[0] = tail_chunks(S, Pw);         // A^512: a frame-major chunk
+        if (d == 8) post_nt[1] = tail_chunks(S, Pw);         // A^8192: a time-contiguous chunk
         mat_mul(S, Pw, Pw, Pw);
     }
     {
@@ -856,6 +1049,9 @@ int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, in
     f->device = device;
     f->S = S;
     f->segment_bytes = kIirSegmentBytes;
+    f->post_nt[0] = post_nt[0];
+    f->post_nt[1] = post_nt[1];
+    f->post_form = -1;
     memcpy(f->A, A_keep, sizeof A_keep);
     hipError_t e = hipMalloc((void **)&f->d_f, sizeof(IirDev));
     if (e == hipSuccess) e = hipMemcpy(f->d_f, &h, sizeof h, hipMemcpyHostToDevice);
@@ -882,7 +1078,7 @@ int zmls_iir_destroy(zmls_iir *f)
         if (f->d_carry) (void)hipFree(f->d_carry);
         for (void *q : f->d_host)
             if (q) (void)hipFree(q);
-        double *fused[5] = {f->d_e, f->d_E, f->d_zi, f->d_sum, f->d_phi};
+        double *fused[8] = {f->d_e, f->d_E, f->d_zi, f->d_sum, f->d_phi, f->d_zeta, f->d_minv, f->d_psi};
         for (double *q : fused)
             if (q) (void)hipFree(q);
     }
@@ -922,6 +1118,18 @@ int zmls_iir_reserve(zmls_iir *f, int64_t n_rows, int64_t n_ch)
         f->group_elems = need_g;
     }
     return ZMLS_OK;
+}
+
+int zmls_iir_set_fused_form(zmls_iir *f, int form)
+{
+    if (!f || form < -1 || form > 1) { set_error("fused form must be -1 (auto), 0 (one sweep in time order) or 1 (filter after the transform)"); return ZMLS_E_ARG; }
+    f->post_form = form;
+    return ZMLS_OK;
+}
+
+int zmls_iir_last_fused_form(const zmls_iir *f)
+{
+    return f ? f->last_form : -1;
 }
 
 int zmls_iir_set_segment(zmls_iir *f, size_t bytes)
@@ -976,12 +1184,15 @@ int zmls_iir_reserve_fused(zmls_iir *f, zmls_plan *p, int64_t n_rows, int64_t n_
     if (rc) return rc;
     const int64_t tt = (256 / 16) * kIirSub;                   // the shorter chunk (frame-major tiles)
     const size_t n_chunks = (size_t)((L + tt - 1) / tt);
-    rc = grow(&f->d_e, &f->e_elems, (size_t)(R - 1) * n_chunks * (size_t)n_ch * (size_t)f->S);
-    if (!rc) rc = grow(&f->d_E, &f->E_elems, (size_t)(R - 1) * (size_t)n_ch * (size_t)f->S);
+    const size_t nt_max = (size_t)std::max(f->post_nt[0], f->post_nt[1]);
+    rc = grow(&f->d_e, &f->e_elems, std::max((size_t)(R - 1) * n_chunks, (size_t)(R + 1) * nt_max) * (size_t)n_ch * (size_t)f->S);
+    if (!rc) rc = grow(&f->d_E, &f->E_elems, (size_t)(R + 1) * (size_t)n_ch * (size_t)f->S);     // the post-filter form: all R periods and the response
     if (!rc) rc = grow(&f->d_zi, &f->zi_elems, (size_t)n_ch * (size_t)f->S);
+    if (!rc) rc = grow(&f->d_zeta, &f->zeta_elems, (size_t)n_ch * (size_t)f->S);
     if (!rc) rc = grow(&f->d_sum, &f->sum_elems, (size_t)L * (size_t)n_ch);
     if (rc) return rc;
     if (!f->d_phi) ZHIP(hipMalloc((void **)&f->d_phi, sizeof(double) * kIirMaxS * kIirMaxS));
+    if (!f->d_minv) ZHIP(hipMalloc((void **)&f->d_minv, sizeof(double) * kIirMaxS * kIirMaxS));
     if (f->phi_L != L) {
         // A^L by binary powers, in long double like the other powers
         const int S = f->S;
@@ -992,15 +1203,99 @@ int zmls_iir_reserve_fused(zmls_iir *f, zmls_plan *p, int64_t n_rows, int64_t n_
             if (k & 1) mat_mul(S, Bm, Rm, Rm);
             mat_mul(S, Bm, Bm, Bm);
         }
-        double phi[kIirMaxS * kIirMaxS] = {0};
+        double phi[kIirMaxS * kIirMaxS] = {0}, minv[kIirMaxS * kIirMaxS] = {0};
         for (int i = 0; i < S; ++i)
             for (int j = 0; j < S; ++j) phi[i * kIirMaxS + j] = (double)Rm[i * S + j];
+        // (I - A^L)^-1: the periodic steady state of a period with zero-state end state E starts from this times E
+        for (int i = 0; i < S * S; ++i) Rm[i] = -Rm[i];
+        for (int i = 0; i < S; ++i) Rm[i * S + i] += 1.0L;
+        if (!mat_inv(S, Rm)) f->post_nt[0] = f->post_nt[1] = 0;       // a pole on the unit circle: no such state (and no tail: both were 0 already)
+        else
+            for (int i = 0; i < S; ++i)
+                for (int j = 0; j < S; ++j) minv[i * kIirMaxS + j] = (double)Rm[i * S + j];
         ZHIP(hipMemcpy(f->d_phi, phi, sizeof phi, hipMemcpyHostToDevice));
+        ZHIP(hipMemcpy(f->d_minv, minv, sizeof minv, hipMemcpyHostToDevice));
         f->phi_L = L;
+        f->psi_L = 0;
     }
     // the transform reads the filtered sums as float64 frames: a float32 plan, an odd channel count or a
     // time-contiguous capture take the layout adapters
-    return zmls_plan_reserve_staging(p, n_ch);
+    rc = zmls_plan_reserve_staging(p, n_ch);
+    if (rc) return rc;
+    // the post-filter form: psi = the plan's responses to the filter's S zero-input sequences, u_k[n] = (A^n e_k)[0], made by the
+    // filter itself (zeros in, the unit states as initial states) and the plan itself (one period, no scaling)
+    if (p->dtype == ZMLS_F64 && (f->post_nt[0] || f->post_nt[1]) && (f->psi_L != L || f->psi_G != p->G)) {
+        const int S = f->S;
+        rc = zmls_plan_reserve_staging(p, S);
+        if (!rc) rc = zmls_iir_reserve(f, L, std::max<int64_t>(n_ch, S));
+        if (!rc) rc = grow(&f->d_psi, &f->psi_elems, (size_t)L * (size_t)S);
+        if (rc) return rc;
+        double *d_u = nullptr, *d_unit = nullptr;
+        double unit[kIirMaxS * kIirMaxS] = {0};
+        for (int i = 0; i < S; ++i) unit[i * S + i] = 1.0;
+        hipError_t e = hipMalloc((void **)&d_u, (size_t)L * S * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_unit, sizeof unit);
+        if (e == hipSuccess) e = hipMemset(d_u, 0, (size_t)L * S * 8);
+        if (e == hipSuccess) e = hipMemcpy(d_unit, unit, sizeof unit, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "zero-input responses");
+#define ZZIR(SS) case SS: rc = launch_iir_cc<SS>(false, f->d_f, d_u, ZMLS_F64, L, S, S, 1, f->d_zc, f->d_sin, f->d_zg, f->d_sg, d_u, S, 1, d_unit, nullptr, 0, nullptr); break;
+        if (!rc) switch (S) {
+            ZZIR(1) ZZIR(2) ZZIR(3) ZZIR(4) ZZIR(5) ZZIR(6) ZZIR(7) ZZIR(8)
+        default: break;
+        }
+#undef ZZIR
+        if (!rc) {
+            const int k = p->in_scale_log2;
+            p->in_scale_log2 = 0;
+            rc = impulse_device_core(p, d_u, ZMLS_F64, 1, 0, 1, S, S, 1, f->d_psi, S, 1, nullptr, nullptr, nullptr, 0);
+            p->in_scale_log2 = k;
+        }
+        e = hipDeviceSynchronize();
+        if (!rc && e != hipSuccess) rc = hip_fail(e, "zero-input responses");
+        if (d_u) (void)hipFree(d_u);
+        if (d_unit) (void)hipFree(d_unit);
+        if (rc) return rc;
+        f->psi_L = L;
+        f->psi_G = p->G;
+    }
+    return ZMLS_OK;
+}
+
+// The post-filter form of the fused call: filter and transform commute up to a rank-S term. With S_x the averaged period, g_c the
+// filter's impulse response folded modulo L and E(.) the zero-state end state of one period,
+//     lfilter(S_x, zi = Zm) = g_c (*) S_x + ZIR(Zm - (I - A^L)^-1 E(S_x))              ((*) circular convolution),
+// the circular cross-correlation with the sequence commutes with (*), and ZIR(zeta) = sum_k zeta_k u_k, so
+//     h = g_c (*) h_plain + sum_k zeta_k psi_k,       g_c (*) h_plain = lfilter(h_plain, zi = (I - A^L)^-1 E(h_plain)).
+// The capture goes through the ordinary gather pass (13.0 instead of 12.4 + 1.6 ms for the headline batch), the filter runs over
+// the responses in place with the rank-S term added on its way out, and the end states E_r come from the last post_nt chunks of
+// every period: 1e-22 of anything earlier is left there (tail_chunks).
+static int impulse_filtered_post(zmls_plan *p, zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs,
+                                 double *d_h, int64_t ors, int64_t ocs, bool tc_in, bool tc_out, hipStream_t st)
+{
+    const int64_t L = p->L, R = n_rows / L;
+    const int S = f->S;
+    const int nt_in = f->post_nt[tc_in ? 1 : 0], nt_out = f->post_nt[tc_out ? 1 : 0];
+    double *e_out = f->d_e + (size_t)R * (size_t)nt_in * (size_t)n_ch * (size_t)S;
+    double *E_out = f->d_E + (size_t)R * (size_t)n_ch * (size_t)S;
+    int rc = ZMLS_OK;
+    ZDEVICE(f->device);
+#define ZTAIL(SS) case SS: \
+        rc = launch_tail_s<SS>(tc_in, f->d_f, d_x, in_dtype, L, R, n_ch, rs, cs, nt_in, f->d_e, f->d_E, st); \
+        if (!rc) rc = impulse_device_core(p, d_x, in_dtype, R - 1, 1, R - 1, n_ch, rs, cs, d_h, ors, ocs, st, nullptr, nullptr, 0); \
+        if (!rc) rc = launch_tail_s<SS>(tc_out, f->d_f, d_h, ZMLS_F64, L, 1, n_ch, ors, ocs, nt_out, e_out, E_out, st); \
+        if (!rc) { \
+            hipLaunchKernelGGL(iir_post_state_kernel<SS>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, (const double *)f->d_phi, (const double *)f->d_minv, \
+                               (int)R, n_ch, (const double *)f->d_E, ldexp(1.0, -p->in_scale_log2), f->d_zeta, f->d_zi); \
+            rc = launch_iir_cc<SS>(tc_out, f->d_f, d_h, ZMLS_F64, L, n_ch, ors, ocs, f->d_zc, f->d_sin, f->d_zg, f->d_sg, d_h, ors, ocs, f->d_zi, \
+                                   (size_t)n_ch * (size_t)S <= f->carry_elems ? f->d_carry : nullptr, f->segment_bytes, st, f->d_psi, f->d_zeta); \
+        } \
+        break;
+    switch (S) {
+        ZTAIL(1) ZTAIL(2) ZTAIL(3) ZTAIL(4) ZTAIL(5) ZTAIL(6) ZTAIL(7) ZTAIL(8)
+    default: set_error("no filter kernel for order %d", S); return ZMLS_E_UNSUPPORTED;
+    }
+#undef ZTAIL
+    return rc;
 }
 
 int zmls_impulse_filtered_device(zmls_plan *p, zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t row_stride,
@@ -1011,6 +1306,24 @@ int zmls_impulse_filtered_device(zmls_plan *p, zmls_iir *f, const void *d_x, int
     const double *sums = nullptr;
     int64_t srs = 0, scs = 0;
     hipStream_t st = (hipStream_t)stream;
+    if (p && f && d_x && p->device == f->device && p->dtype == ZMLS_F64 && dtype_size(in_dtype) && n_ch >= 1 && row_stride >= 1 && ch_stride >= 1 &&
+        f->post_form != 0 && (kPostForm() || f->post_form == 1) && n_rows > p->L && n_rows % p->L == 0 && n_rows / p->L <= 0x7FFFFFFF && f->phi_L == p->L &&
+        f->psi_L == p->L && f->psi_G == p->G) {
+        // the post-filter form: when the filter's memory is a small part of a period (else the tails are most of the capture)
+        const int64_t L = p->L, R = n_rows / L;
+        const bool tc_in = row_stride == 1 && (n_ch == 1 || ch_stride != 1), tc_out = out_row_stride == 1 && (n_ch == 1 || out_ch_stride != 1);
+        const int64_t nt_in = f->post_nt[tc_in ? 1 : 0], nt_out = f->post_nt[tc_out ? 1 : 0];
+        const int64_t tt_in = tc_in ? 8192 : 512, tt_out = tc_out ? 8192 : 512;
+        const int64_t share = f->post_form == 1 ? 1 : 4;            // auto: the tails are at most a quarter of the capture
+        const bool short_memory = nt_in > 0 && nt_out > 0 && nt_in * tt_in * share <= L && nt_out * tt_out * share <= L;
+        const bool room = (size_t)(R * nt_in + nt_out) * (size_t)n_ch * (size_t)f->S <= f->e_elems && (size_t)(R + 1) * (size_t)n_ch * (size_t)f->S <= f->E_elems &&
+                          (size_t)n_ch * (size_t)f->S <= std::min(f->zi_elems, f->zeta_elems) && (size_t)L * (size_t)f->S <= f->psi_elems &&
+                          !iir_scratch_check(f, L, n_ch, tt_out);
+        f->last_form = (short_memory && room) ? 1 : 0;
+        if (short_memory && room)
+            return impulse_filtered_post(p, f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, (double *)d_h, out_row_stride, out_ch_stride, tc_in, tc_out, st);
+    }
+    if (f) f->last_form = 0;
     int rc = filtered_period_sums(p, f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, &sums, &srs, &scs, st);
     if (rc) return rc;
     // one period of filtered sums -> divided by the period count in the gather, transformed, scattered

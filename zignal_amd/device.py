@@ -313,6 +313,14 @@ class IirFilter:
         """bytes of signal per segment of the time axis (tests / tuning): None the library's own size, 0 one segment"""
         L.check(L.lib().zmls_iir_set_segment(self._h, ctypes.c_size_t(-1).value if nbytes is None else int(nbytes)))
 
+    def set_fused_form(self, form=-1):
+        """which form Plan.impulse_filtered_device takes (tests / tuning): 0 one sweep in time order, 1 the filter after the
+        transform, -1 the library's choice (zmls_iir_set_fused_form)"""
+        L.check(L.lib().zmls_iir_set_fused_form(self._h, int(form)))
+
+    def last_fused_form(self):
+        return int(L.lib().zmls_iir_last_fused_form(self._h))
+
     def reserve_fused(self, plan, n_rows, n_ch):
         """scratch for Plan.impulse_filtered_device on captures of n_rows frames x n_ch channels (zmls_iir_reserve_fused)"""
         L.check(L.lib().zmls_iir_reserve_fused(self._h, plan._h, int(n_rows), int(n_ch)))
