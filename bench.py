@@ -454,8 +454,9 @@ def next_rows(dev):
         sp.close(); h.free(); m.free()
     N, C, R = 20, 512, 17
     L = (1 << N) - 1
-    B, A = [1.0, -1.9, 0.9], [1.2, -1.8, 0.7]                    # a minimum-phase biquad and its inverse, like MLS's emphasis pair
-    f = IirFilter(A, B, device=dev)
+    from zignal_amd.filters.biquads import RBJ
+    B, A = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=96000).get_coefficients()   # MLS_simple's emphasis filter (mls.py:433)
+    f = IirFilter(A, B, device=dev)                              # de-emphasis: its inverse (mls.py:365-366)
     x = DeviceBuffer(R * L * C * 8, dev); x.fill(0)
     y = DeviceBuffer(2 * L * C * 8, dev)
     f.reserve(2 * L, C)
@@ -466,6 +467,7 @@ def next_rows(dev):
     hh = DeviceBuffer(L * C * 8, dev)
     f.reserve_fused(p, R * L, C)
     rows["deemphasis_fused_with_impulse_N20_x512_x17_ms"] = timed(lambda: p.impulse_filtered_device(f, x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, hh.ptr, C, 1), 3)
+    rows["deemphasis_fused_form"] = ("filter after the transform" if f.last_fused_form() == 1 else "one sweep in time order") + " (DESIGN.md §9)"
     rows["impulse_same_capture_ms"] = timed(lambda: p.impulse_device(x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, hh.ptr, C, 1), 3)
     x.free(); hh.free(); f.close(); p.close()
     rows["what"] = ("device time per call, synthetic data: magnitude response (Audio.fft, own transform passes) of N=20 responses; the emphasis "

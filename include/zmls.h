@@ -247,7 +247,10 @@ int zmls_iir_device(zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, 
  * (mls.py:409-414), the chain MLS_simple.get_impulse runs (mls.py:454-458): h = get_impulse(lfilter(b, a, x)) for n_ch
  * channels. Filter and average are linear, so the capture is swept ONCE (periods added up, the filter's state at
  * every period boundary taken beside it) and the filter itself runs over one period of sums from the summed states
- * (iir.hip): nothing of the capture's size is written. x as in zmls_impulse_device (n_rows = R*L frames, period 0
+ * (iir.hip): nothing of the capture's size is written. Where the filter's memory is a small part of a period (and the
+ * plan is float64) the filter runs AFTER the transform instead - it commutes with the circular cross-correlation up to
+ * a rank-S term that the last frames of every period determine - so the capture takes the ordinary gather pass
+ * (impulse_filtered_post in iir.hip; same result to rounding). x as in zmls_impulse_device (n_rows = R*L frames, period 0
  * filtered but not averaged), h in the plan's dtype. zmls_iir_reserve_fused allocates (outside timed regions);
  * the launch call never allocates or synchronises. */
 int zmls_iir_reserve_fused(zmls_iir *f, zmls_plan *p, int64_t n_rows, int64_t n_ch);

@@ -63,17 +63,24 @@ two = timed(lambda: (f.filter_device(x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, y.ptr
                      p.impulse_device(y.ptr, _lib.ZMLS_F64, R * L, C, C, 1, h.ptr, C, 1)), 3)
 y.free()
 f.reserve_fused(p, R * L, C)
+f.set_fused_form(0)
+sweep = timed(lambda: p.impulse_filtered_device(f, x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, h.ptr, C, 1), 3)
+f.set_fused_form(-1)
 one = timed(lambda: p.impulse_filtered_device(f, x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, h.ptr, C, 1), 3)
-print("de-emphasis + impulse, N=%d x %d channels x %d periods: filter then transform %8.3f ms, fused %8.3f ms (%.0f GB/s of capture read)"
-      % (N, C, R, two, one, R * L * C * 8 / one / 1e6), flush=True)
+print("de-emphasis + impulse, N=%d x %d channels x %d periods: filter then transform %8.3f ms, fused: sweep form %8.3f ms, library's choice (form %d) %8.3f ms (%.0f GB/s of capture read)"
+      % (N, C, R, two, sweep, f.last_fused_form(), one, R * L * C * 8 / one / 1e6), flush=True)
 x1 = DeviceBuffer(R * L * 8); x1.fill(0)
 h1 = DeviceBuffer(L * 8)
 f.reserve(R * L, 1); f.reserve_fused(p, R * L, 1)
 y1 = DeviceBuffer(R * L * 8)
 two = timed(lambda: (f.filter_device(x1.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, y1.ptr, 1, 1),
                      p.impulse_device(y1.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, h1.ptr, 1, 1)), 5)
+f.set_fused_form(0)
+sweep = timed(lambda: p.impulse_filtered_device(f, x1.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, h1.ptr, 1, 1), 5)
+f.set_fused_form(-1)
 one = timed(lambda: p.impulse_filtered_device(f, x1.ptr, _lib.ZMLS_F64, R * L, 1, 1, 1, h1.ptr, 1, 1), 5)
-print("de-emphasis + impulse, N=%d, one channel x %d periods (the reference's shape): filter then transform %8.3f ms, fused %8.3f ms" % (N, R, two, one), flush=True)
+print("de-emphasis + impulse, N=%d, one channel x %d periods (the reference's shape): filter then transform %8.3f ms, fused: sweep form %8.3f ms, library's choice (form %d) %8.3f ms"
+      % (N, R, two, sweep, f.last_fused_form(), one), flush=True)
 
 # several sources at once (mls.py:338-343): K plans over one capture, one call per source against zmls_impulse_sources_device
 from zignal_amd.device import Sources
