@@ -313,6 +313,36 @@ def test_post_filter_form_choice_and_raw_pcm_scale():
     f.close()
 
 
+def test_post_filter_form_with_segments_of_the_time_axis_and_float32_captures():
+    """the rank-S term rides in the filter's second sweep: with the time axis cut into segments (zmls_iir_set_segment) every
+    segment must pick its own rows of psi; float32 captures go through the layout adapter first"""
+    from gpu_common import plan
+    N, C, R = 17, 256, 2                  # 16 channel groups: a segment is at least 128 chunks = 65536 of the 131071 frames (launch_iir_s)
+    taps = TAPS[N][0]
+    p = plan(N, taps)
+    rng = np.random.default_rng(5)
+    b, a = stable_filter(3, rng)
+    f = IirFilter(b, a, device=0)
+    x = rng.standard_normal((R * p.L, C))
+    want, _ = _fused_form(p, f, x, 0)
+    whole, took = _fused_form(p, f, x, 1)
+    assert took == 1 and rel_err(whole, want) <= 1e-13
+    for seg in (1 << 20, 160 << 20):      # two segments (the smallest there are); 80000 frames and the rest
+        f.set_segment(seg)
+        got, took = _fused_form(p, f, x, 1)
+        assert took == 1 and rel_err(got, want) <= 1e-13, seg
+        assert not np.array_equal(got, whole), "the segments were not cut: the start states of the second one come by another route"
+    x = x[:, :8].copy()
+    want, _ = _fused_form(p, f, x, 0)
+    f.set_segment(None)
+    x32 = x.astype(np.float32)
+    assert rel_err(_fused_form(p, f, x, 1)[0], want) <= 1e-13
+    want32, _ = _fused_form(p, f, x32, 0)
+    got32, took = _fused_form(p, f, x32, 1)
+    assert took == 1 and rel_err(got32, want32) <= 1e-13
+    f.close()
+
+
 def test_mls_get_impulses_deemphasised_many_channels():
     N, R, C = 12, 4, 6
     b, a = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=48000).get_coefficients()
