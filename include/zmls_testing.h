@@ -104,6 +104,14 @@ int zmls_iir_set_segment(zmls_iir *f, size_t bytes);
  * linear map (mls.py:401-414: apply_deemphasis, then get_impulse): results agree to rounding. zmls_iir_last_fused_form: the form
  * the most recent call took (0 / 1; -1 for a null filter). No reference counterpart. */
 int zmls_iir_set_fused_form(zmls_iir *f, int form);
+
+/* Tests / tuning: the one-sweep form of the filter (csrc/iir.hip, iir_once_kernel). For filters whose memory is short (A^n below
+ * 1e-22 after a few chunks) a workgroup walks `chunks_per_workgroup` chunks in time order carrying the state, after a warm-up over
+ * the chunks before its first: the signal is read 1 + warm-up / chunks_per_workgroup times instead of twice. Never in place (the
+ * library checks for overlapping buffers) and never with zmls_iir_set_segment. -1 (default): where the warm-up is at most a
+ * quarter of a workgroup's work and 1024 workgroups remain; 0: never; 1: wherever it can run, with the given chunk count.
+ * Same per-sample arithmetic; start states equal to 1e-22 of the state's size. No reference counterpart. */
+int zmls_iir_set_one_sweep(zmls_iir *f, int mode, int chunks_per_workgroup);
 int zmls_iir_last_fused_form(const zmls_iir *f);
 
 /* Profiling: how many kernels the most recent impulse call on this plan launched, by kind - out[0] first (gather) pass, out[1]

@@ -269,6 +269,11 @@ def test_post_filter_form_of_the_fused_call(N, C, R, order, stacked_in, stacked_
     assert rel_err(post, sweep) <= 1e-13
     if N <= 16:
         assert rel_err(post, _reference_chain(N, taps, b, a, x)) <= TOL
+    for mode, m in ((1, 3), (0, 0)):                        # the filter over the responses in its one-sweep form (forced), and never
+        f.set_one_sweep(mode, m)
+        got, took = _fused_form(p, f, x, 1, stacked_in, stacked_out)
+        assert took == 1 and rel_err(got, sweep) <= 1e-13, (mode, m)
+    f.set_one_sweep(-1)
     # again on the same filter and plan (the tail and state arrays are reused), with a shorter capture
     if R > 2:
         x2 = x[:2 * p.L]
@@ -341,6 +346,49 @@ def test_post_filter_form_with_segments_of_the_time_axis_and_float32_captures():
     got32, took = _fused_form(p, f, x32, 1)
     assert took == 1 and rel_err(got32, want32) <= 1e-13
     f.close()
+
+
+@pytest.mark.parametrize("shape,layout,dtype,order,M", [((70000, 3), "frames", np.float64, 2, 1), ((20011, 16), "frames", np.float64, 5, 3),
+                                                        ((300007, 6), "frames", np.float64, 8, 8), ((1 << 20, 1), "time", np.float64, 2, 2),
+                                                        ((1 << 17, 3), "stacked", np.float64, 3, 5), ((90000, 37), "frames", np.float32, 4, 2),
+                                                        ((50000, 5), "frames", np.int16, 1, 7), ((700, 5), "frames", np.float64, 2, 4)])
+def test_one_sweep_form_for_short_memory_filters(shape, layout, dtype, order, M):
+    """round 3 (csrc/iir.hip, iir_once_kernel): a workgroup walks M chunks carrying the state after a warm-up over the chunks that
+    still ring at its first one; forced here with small M (many workgroups, many warm-ups) against the two sweeps and lfilter.
+    In place the library must fall back to the two sweeps by itself."""
+    rng = np.random.default_rng(shape[0] % 9973 + M)
+    n, C = shape
+    x = (rng.standard_normal(shape) * 1000).astype(dtype)
+    B, A = stable_filter(order, rng)
+    f = IirFilter(B, A, device=0)
+    f.reserve(n, C)
+    host = np.ascontiguousarray(x.T) if layout == "stacked" else x
+    rs, cs = (1, n) if layout == "stacked" else (C, 1)
+    dx = DeviceBuffer(host.nbytes).upload(host)
+    dy = DeviceBuffer(n * C * 8)
+    want = scipy.signal.lfilter(B, A, x.astype(np.float64), axis=0)
+
+    def run(mode, m=0, src=None):
+        f.set_one_sweep(mode, m)
+        if src is None:
+            dy.fill(0xFF)
+        f.filter_device((src or dx).ptr, _lib.dtype_code(host.dtype) if src is None else _lib.ZMLS_F64, n, C, rs, cs, dy.ptr, rs, cs)
+        sync(0)
+        out = dy.download(host.shape, np.float64)
+        return out.T if layout == "stacked" else out
+
+    two = run(0)
+    assert rel_err(two, want) <= TOL
+    one = run(1, M)
+    assert rel_err(one, want) <= TOL and rel_err(one, two) <= 1e-13
+    assert np.array_equal(run(1, M), one), "same bits every time"
+    assert rel_err(run(1, 4096), want) <= TOL               # one workgroup per channel group walks the whole signal: no warm-up at all
+    assert rel_err(run(-1), want) <= TOL
+    if dtype == np.float64:
+        dy.upload(host)                                      # in place: the warm-up would read outputs - the two sweeps run instead
+        assert np.array_equal(run(1, M, src=dy), two)
+    f.set_one_sweep(-1)
+    dx.free(); dy.free(); f.close()
 
 
 def test_mls_get_impulses_deemphasised_many_channels():

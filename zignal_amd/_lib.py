@@ -39,6 +39,7 @@ SIGNATURES = {
     "zmls_plan_last_launches": [c_vp, c_vp],
     "zmls_iir_set_segment": [c_vp, c_sz],
     "zmls_iir_set_fused_form": [c_vp, c_int],
+    "zmls_iir_set_one_sweep": [c_vp, c_int, c_int],
     "zmls_iir_last_fused_form": [c_vp],
     "zmls_plan_set_input_scale_log2": [c_vp, c_int],
     "zmls_plan_info": [c_vp, ctypes.POINTER(c_i64)],

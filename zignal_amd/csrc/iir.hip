@@ -348,14 +348,165 @@ __global__ void __launch_bounds__(64) iir_carry_kernel(const IirDev *__restrict_
     for (int k = 0; k < S; ++k) carry[c * S + k] = e[k];
 }
 
+
+// ---- one sweep for filters with a short memory (round 3). When A^n is below 1e-22 after nt chunks (tail_chunks), the filter state at
+// a chunk boundary is known from the nt chunks before it alone: a workgroup walks M chunks in time order carrying the state in LDS,
+// after a warm-up over the nt chunks before its first (read again, nothing written; the first workgroup of the signal starts from the
+// initial state instead). The signal is read 1 + nt/M times and written once, instead of read twice. Per chunk the same steps as
+// iir_chunk_kernel's second sweep: zero-state runs, scan, true start states, rerun, coalesced store. Not in place: the warm-up reads
+// what the workgroup before may already have overwritten.
+template <int S, int CC>
+__device__ __forceinline__ void chunk_end_state(const IirDev *__restrict__ f, const double *tile, double *sc, int tid, double (&z)[S]);   // further down
+
+template <int S, int CC, int MODE /* 1: outputs, 2: with the rank-S term of the post-filter form */>
+__global__ void __launch_bounds__(256) iir_once_kernel(const IirDev *__restrict__ f, const void *__restrict__ x, int in_dtype, int64_t n_rows, int64_t n_ch,
+                                                       int64_t rs, int64_t cs, uint32_t n_cgrp, int M, int nt, const double *__restrict__ zi,
+                                                       double *__restrict__ y, int64_t ors, int64_t ocs, const double *__restrict__ psi,
+                                                       const double *__restrict__ zeta)
+{
+    constexpr int NB = 256 / CC;
+    constexpr int LOGNB = (CC == 1) ? 8 : 4;
+    constexpr int TT = NB * kIirSub;
+    constexpr int PER = TT * CC / 256;
+    __shared__ double tile[256 * kIirPitch];
+    __shared__ double sc[256 * S];
+    __shared__ double psl[(MODE == 2 && CC == 16) ? TT * S : 1];
+    __shared__ double carry[CC * S];
+    const int tid = threadIdx.x;
+    const uint32_t bid = (CC > 1 && gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int64_t sup = bid / n_cgrp, c0 = (int64_t)(bid % n_cgrp) * CC;
+    const int64_t n_chunks = (n_rows + TT - 1) / TT;
+    const int64_t q_first = sup * M;
+    const int64_t q_begin = q_first - nt > 0 ? q_first - nt : 0, q_end = q_first + M < n_chunks ? q_first + M : n_chunks;
+    const int sb = tid / CC, ccl = tid % CC;
+    const int64_t c = c0 + ccl;
+    if (tid < CC * S) {
+        const int64_t ch = c0 + tid / S;
+        carry[tid] = (q_begin == 0 && zi && ch < n_ch) ? zi[ch * S + tid % S] : 0.0;
+    }
+    double zt[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) zt[k] = (MODE == 2 && c < n_ch) ? zeta[c * S + k] : 0.0;
+    for (int64_t q = q_begin; q < q_end; ++q) {
+        const int64_t t0 = q * TT;
+        const bool out = q >= q_first;
+        if constexpr (MODE == 2 && CC == 16) {
+            if (out) {
+                const int64_t have = (n_rows - t0 < TT ? n_rows - t0 : TT) * S;
+#pragma unroll
+                for (int i = 0; i < TT * S / 256; ++i) psl[tid + i * 256] = (tid + i * 256 < have) ? psi[t0 * S + tid + i * 256] : 0.0;
+            }
+        }
+        if (in_dtype == ZMLS_F64 && t0 + TT <= n_rows && c0 + CC <= n_ch) {
+            double r[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = tid + i * 256, tt = e / CC, cc = e % CC;
+                r[i] = __builtin_nontemporal_load((const double *)x + (t0 + tt) * rs + (c0 + cc) * cs);
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = tid + i * 256, tt = e / CC, cc = e % CC;
+                tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)] = r[i];
+            }
+        } else {
+            for (int e = tid; e < TT * CC; e += 256) {
+                const int tt = e / CC, cc = e % CC;
+                const int64_t t = t0 + tt, ch = c0 + cc;
+                tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)] = (t < n_rows && ch < n_ch) ? iir_load(x, t * rs + ch * cs, in_dtype) : 0.0;
+            }
+        }
+        __syncthreads();                          // the tile, psl and the carried state are in LDS
+        double v[S], w[S];
+        chunk_end_state<S, CC>(f, tile, sc, tid, v);       // inclusive scan of the runs' zero-state end states (ends with a barrier)
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            sc[tid * S + k] = v[k];
+            w[k] = carry[ccl * S + k];
+        }
+        __syncthreads();
+        double z[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) z[k] = sb > 0 ? sc[(tid - CC) * S + k] : 0.0;
+#pragma unroll
+        for (int d = 0; d < LOGNB; ++d) {
+            if ((sb >> d) & 1) {
+                double r[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) r[k] = 0.0;
+                matvec_acc<S>(f->P[d], w, r);
+#pragma unroll
+                for (int k = 0; k < S; ++k) w[k] = r[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) z[k] += w[k];
+#pragma unroll 4
+        for (int i = 0; i < kIirSub; ++i) tile[tid * kIirPitch + i] = df2t_step<S>(f, tile[tid * kIirPitch + i], z);
+        if (sb == NB - 1) {                       // the last run's state after its rerun is the state at the end of the chunk
+#pragma unroll
+            for (int k = 0; k < S; ++k) carry[ccl * S + k] = z[k];
+        }
+        __syncthreads();
+        if (out) {
+            for (int e = tid; e < TT * CC; e += 256) {
+                const int tt = e / CC, cc = e % CC;
+                const int64_t t = t0 + tt, ch = c0 + cc;
+                if (t < n_rows && ch < n_ch) {
+                    double o = tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)];
+                    if constexpr (MODE == 2) {
+                        const double *ps = (CC == 16) ? psl + tt * S : psi + t * S;
+#pragma unroll
+                        for (int k = 0; k < S; ++k) o = __builtin_fma(zt[k], ps[k], o);
+                    }
+                    __builtin_nontemporal_store(o, y + t * ors + ch * ocs);
+                }
+            }
+            __syncthreads();                      // before the next chunk's loads overwrite the tile
+        }
+    }
+}
+
+// ZMLS_IIR_ONCE=0 (tuning): always the two sweeps
+static bool kOnceSweep()
+{
+    static const bool on = [] { const char *v = getenv("ZMLS_IIR_ONCE"); return !(v && *v == '0'); }();
+    return on;
+}
+
 template <int S, int CC>
 int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs, double *d_zc, double *d_sin,
                  double *d_zg, double *d_sg, double *d_y, int64_t ors, int64_t ocs, const double *d_zi, double *d_carry, size_t segment_bytes,
-                 hipStream_t st, const double *d_psi = nullptr, const double *d_zeta = nullptr)
+                 hipStream_t st, const double *d_psi = nullptr, const double *d_zeta = nullptr, int nt_once = 0, int once_M = 0)
 {
     constexpr int NB = 256 / CC, TT = NB * kIirSub, LOGNB = (CC == 1) ? 8 : 4;
     const uint64_t n_cgrp = (uint64_t)((n_ch + CC - 1) / CC);
     if (n_cgrp * (uint64_t)((n_rows + TT - 1) / TT) == 0 || n_cgrp * (uint64_t)((n_rows + TT - 1) / TT) > 0x7FFFFFFFull) { set_error("filter grid out of range"); return ZMLS_E_ARG; }
+    if (nt_once > 0 && !(segment_bytes && d_carry) && kOnceSweep()) {
+        // one sweep (iir_once_kernel): not in place, and only when a workgroup's warm-up is a small part of its work and there are
+        // still workgroups enough to fill the GPU twice over
+        const size_t is0 = dtype_size(in_dtype);
+        const char *xb = (const char *)d_x, *xe = xb + (size_t)((n_rows - 1) * rs + (n_ch - 1) * cs + 1) * is0;
+        const char *yb = (const char *)d_y, *ye = yb + (size_t)((n_rows - 1) * ors + (n_ch - 1) * ocs + 1) * 8;
+        const uint64_t n_chunks = (uint64_t)((n_rows + TT - 1) / TT);
+        int M = once_M > 0 ? once_M : 0;              // forced (tests): any number of chunks per workgroup, any grid
+        for (int mult : {8, 4}) {
+            if (M) break;
+            const uint64_t m = (uint64_t)std::max(8, mult * nt_once);
+            if (n_cgrp * ((n_chunks + m - 1) / m) >= 1024) { M = (int)m; break; }
+        }
+        if (M && (xe <= yb || ye <= xb)) {
+            const uint64_t blocks = n_cgrp * ((n_chunks + M - 1) / M);
+            if (d_psi)
+                hipLaunchKernelGGL((iir_once_kernel<S, CC, 2>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, (uint32_t)n_cgrp, M,
+                                   nt_once, d_zi, d_y, ors, ocs, d_psi, d_zeta);
+            else
+                hipLaunchKernelGGL((iir_once_kernel<S, CC, 1>), dim3((uint32_t)blocks), dim3(256), 0, st, d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, (uint32_t)n_cgrp, M,
+                                   nt_once, d_zi, d_y, ors, ocs, (const double *)nullptr, (const double *)nullptr);
+            ZHIP(hipGetLastError());
+            return ZMLS_OK;
+        }
+    }
     // Segments of the time axis (round 3, a tuning option that is OFF by default): the signal is swept twice, and a segment
     // small enough to stay in the 256 MiB Infinity Cache between its two sweeps could be read from HBM once. Whole chunks per
     // segment, all channels; the state after a segment's last chunk (iir_carry_kernel) is the next segment's initial state.
@@ -421,14 +572,14 @@ int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_row
 template <int S>
 int launch_iir_cc(bool time_contiguous, const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_rows, int64_t n_ch, int64_t rs, int64_t cs,
                   double *d_zc, double *d_sin, double *d_zg, double *d_sg, double *d_y, int64_t ors, int64_t ocs, const double *d_zi, double *d_carry,
-                  size_t segment_bytes, hipStream_t st, const double *d_psi = nullptr, const double *d_zeta = nullptr)
+                  size_t segment_bytes, hipStream_t st, const double *d_psi = nullptr, const double *d_zeta = nullptr, const int *nt_once = nullptr, int once_M = 0)
 {
     // stacked single-channel signals (time-contiguous, several channels) are not cut: a segment of all channels is no contiguous
     // piece of memory there and the channels are far apart anyway
     if (time_contiguous) return launch_iir_s<S, 1>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, d_zi, d_carry,
-                                                   n_ch == 1 ? segment_bytes : 0, st, d_psi, d_zeta);
+                                                   n_ch == 1 ? segment_bytes : 0, st, d_psi, d_zeta, nt_once ? nt_once[1] : 0, once_M);
     return launch_iir_s<S, 16>(d_f, d_x, in_dtype, n_rows, n_ch, rs, cs, d_zc, d_sin, d_zg, d_sg, d_y, ors, ocs, d_zi, d_carry, segment_bytes, st, d_psi,
-                               d_zeta);
+                               d_zeta, nt_once ? nt_once[0] : 0, once_M);
 }
 
 // ---- the fused path: one sweep over the capture (period sums + chunk end states), then two small kernels
@@ -858,6 +1009,7 @@ struct zmls_iir {
     // the post-filter form of the fused path (impulse_filtered_post)
     int post_nt[2];            // chunks at the end of a period that hold all of its end state: [0] frame-major tiles (512 frames), [1] time-contiguous (8192); 0: the filter rings too long
     int post_form;             // -1: the post-filter form where it applies, 0: never, 1: wherever it can run at all (tests)
+    int once_mode, once_M;     // the one-sweep filter (iir_once_kernel): -1 where it pays, 0 never, 1 wherever it can run, once_M chunks per workgroup (tests)
     int last_form;             // which form the most recent zmls_impulse_filtered_device call took: 0 sweep, 1 post-filter
     double *d_zeta, *d_minv, *d_psi;   // per-channel coefficients of the rank-S term, (I - A^L)^-1, responses to the S zero-input basis sequences (L x S)
     size_t zeta_elems, psi_elems;
@@ -1054,6 +1206,7 @@ int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, in
     f->post_nt[0] = post_nt[0];
     f->post_nt[1] = post_nt[1];
     f->post_form = -1;
+    f->once_mode = -1;
     memcpy(f->A, A_keep, sizeof A_keep);
     hipError_t e = hipMalloc((void **)&f->d_f, sizeof(IirDev));
     if (e == hipSuccess) e = hipMemcpy(f->d_f, &h, sizeof h, hipMemcpyHostToDevice);
@@ -1129,6 +1282,17 @@ int zmls_iir_set_fused_form(zmls_iir *f, int form)
     return ZMLS_OK;
 }
 
+int zmls_iir_set_one_sweep(zmls_iir *f, int mode, int chunks_per_workgroup)
+{
+    if (!f || mode < -1 || mode > 1 || (mode == 1 && (chunks_per_workgroup < 1 || chunks_per_workgroup > 65536))) {
+        set_error("one-sweep mode must be -1 (auto), 0 (never) or 1 (forced, with 1..65536 chunks per workgroup)");
+        return ZMLS_E_ARG;
+    }
+    f->once_mode = mode;
+    f->once_M = mode == 1 ? chunks_per_workgroup : 0;
+    return ZMLS_OK;
+}
+
 int zmls_iir_last_fused_form(const zmls_iir *f)
 {
     return f ? f->last_form : -1;
@@ -1154,7 +1318,7 @@ int zmls_iir_device(zmls_iir *f, const void *d_x, int in_dtype, int64_t n_rows, 
     rc = iir_scratch_check(f, n_rows, n_ch, tt);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-#define ZIIR(SS) case SS: return launch_iir_cc<SS>(tc, f->d_f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, f->d_zc, f->d_sin, f->d_zg, f->d_sg, d_y, out_row_stride, out_ch_stride, nullptr, (size_t)n_ch * (size_t)f->S <= f->carry_elems ? f->d_carry : nullptr, f->segment_bytes, st);
+#define ZIIR(SS) case SS: return launch_iir_cc<SS>(tc, f->d_f, d_x, in_dtype, n_rows, n_ch, row_stride, ch_stride, f->d_zc, f->d_sin, f->d_zg, f->d_sg, d_y, out_row_stride, out_ch_stride, nullptr, (size_t)n_ch * (size_t)f->S <= f->carry_elems ? f->d_carry : nullptr, f->segment_bytes, st, nullptr, nullptr, f->once_mode ? f->post_nt : nullptr, f->once_mode > 0 ? f->once_M : 0);
     switch (f->S) {
         ZIIR(1) ZIIR(2) ZIIR(3) ZIIR(4) ZIIR(5) ZIIR(6) ZIIR(7) ZIIR(8)
     default: break;
@@ -1281,15 +1445,20 @@ static int impulse_filtered_post(zmls_plan *p, zmls_iir *f, const void *d_x, int
     double *E_out = f->d_E + (size_t)R * (size_t)n_ch * (size_t)S;
     int rc = ZMLS_OK;
     ZDEVICE(f->device);
+    // frame-major responses: the transform writes them into the filter's own period-sized array and the filter reads them from there,
+    // so that it may take its one-sweep form (iir_once_kernel: not in place); else in place in d_h
+    const bool via = !tc_out && kOnceSweep() && f->once_mode && !f->segment_bytes && (size_t)L * (size_t)n_ch <= f->sum_elems;
+    double *h_mid = via ? f->d_sum : d_h;
+    const int64_t mrs = via ? n_ch : ors, mcs = via ? 1 : ocs;
 #define ZTAIL(SS) case SS: \
         rc = launch_tail_s<SS>(tc_in, f->d_f, d_x, in_dtype, L, R, n_ch, rs, cs, nt_in, f->d_e, f->d_E, st); \
-        if (!rc) rc = impulse_device_core(p, d_x, in_dtype, R - 1, 1, R - 1, n_ch, rs, cs, d_h, ors, ocs, st, nullptr, nullptr, 0); \
-        if (!rc) rc = launch_tail_s<SS>(tc_out, f->d_f, d_h, ZMLS_F64, L, 1, n_ch, ors, ocs, nt_out, e_out, E_out, st); \
+        if (!rc) rc = impulse_device_core(p, d_x, in_dtype, R - 1, 1, R - 1, n_ch, rs, cs, h_mid, mrs, mcs, st, nullptr, nullptr, 0); \
+        if (!rc) rc = launch_tail_s<SS>(tc_out, f->d_f, h_mid, ZMLS_F64, L, 1, n_ch, mrs, mcs, nt_out, e_out, E_out, st); \
         if (!rc) { \
             hipLaunchKernelGGL(iir_post_state_kernel<SS>, dim3((uint32_t)((n_ch + 63) / 64)), dim3(64), 0, st, (const double *)f->d_phi, (const double *)f->d_minv, \
                                (int)R, n_ch, (const double *)f->d_E, ldexp(1.0, -p->in_scale_log2), f->d_zeta, f->d_zi); \
-            rc = launch_iir_cc<SS>(tc_out, f->d_f, d_h, ZMLS_F64, L, n_ch, ors, ocs, f->d_zc, f->d_sin, f->d_zg, f->d_sg, d_h, ors, ocs, f->d_zi, \
-                                   (size_t)n_ch * (size_t)S <= f->carry_elems ? f->d_carry : nullptr, f->segment_bytes, st, f->d_psi, f->d_zeta); \
+            rc = launch_iir_cc<SS>(tc_out, f->d_f, h_mid, ZMLS_F64, L, n_ch, mrs, mcs, f->d_zc, f->d_sin, f->d_zg, f->d_sg, d_h, ors, ocs, f->d_zi, \
+                                   (size_t)n_ch * (size_t)S <= f->carry_elems ? f->d_carry : nullptr, f->segment_bytes, st, f->d_psi, f->d_zeta, f->once_mode ? f->post_nt : nullptr, f->once_mode > 0 ? f->once_M : 0); \
         } \
         break;
     switch (S) {

@@ -318,6 +318,11 @@ class IirFilter:
         transform, -1 the library's choice (zmls_iir_set_fused_form)"""
         L.check(L.lib().zmls_iir_set_fused_form(self._h, int(form)))
 
+    def set_one_sweep(self, mode=-1, chunks_per_workgroup=0):
+        """the one-sweep form of the filter for short-memory filters (tests / tuning): -1 the library's choice, 0 never, 1 forced
+        with that many chunks per workgroup (zmls_iir_set_one_sweep)"""
+        L.check(L.lib().zmls_iir_set_one_sweep(self._h, int(mode), int(chunks_per_workgroup)))
+
     def last_fused_form(self):
         return int(L.lib().zmls_iir_last_fused_form(self._h))
 
