@@ -232,7 +232,9 @@ int zmls_impulse_period_sharded_device(zmls_plan *p, zmls_comm *c, const void *d
 /* ---- emphasis / de-emphasis: replaces Filter.filter_samples = scipy.signal.lfilter(B, A, x, axis=0)
  * (zignal/filters/linearfilter.py:62-63) as MLS.apply_emphasis / apply_deemphasis use it (mls.py:393-407) on the
  * whole stimulus / capture. Same transposed-direct-form-II arithmetic per sample, float64, zero initial state; the
- * recurrence is cut into blocks whose start states are put together with powers of the state matrix (iir.hip).
+ * recurrence is cut into blocks whose start states are put together with powers of the state matrix (iir.hip): two
+ * sweeps over the signal; filters whose memory is short (A^n below 1e-22 within a few blocks) take one sweep with a short
+ * warm-up per workgroup instead, when x and y do not overlap.
  * b, a: numerator / denominator as lfilter takes them (normalised by a[0] here); order max(nb, na)-1 <= 8. */
 int zmls_iir_create(zmls_iir **out, const double *b, int nb, const double *a, int na, int device);
 int zmls_iir_destroy(zmls_iir *f);

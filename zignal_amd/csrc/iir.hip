@@ -20,6 +20,7 @@
 // the sequential ones by rounding only (~1e-16 relative for the stable filters MLS accepts: it asserts minimum
 // phase, mls.py:365-369). All arithmetic is float64, as lfilter's is for float64 coefficients.
 // Streaming: the signal is read twice and written once; integer VALU and LDS are far from limits; bound: HBM.
+// Filters with a short memory read it once (iir_once_kernel, round 3): a workgroup walks several chunks carrying the state.
 //
 // De-emphasis FUSED with the impulse response (zmls_impulse_filtered_device = MLS.apply_deemphasis + get_impulse,
 // mls.py:401-414, as MLS_simple.get_impulse chains them, mls.py:454-458). Filtering R periods and then averaging R-1 of
