@@ -109,7 +109,7 @@ int zmls_iir_set_fused_form(zmls_iir *f, int form);
  * 1e-22 after a few chunks) a workgroup walks `chunks_per_workgroup` chunks in time order carrying the state, after a warm-up over
  * the chunks before its first: the signal is read 1 + warm-up / chunks_per_workgroup times instead of twice. Never in place (the
  * library checks for overlapping buffers) and never with zmls_iir_set_segment. -1 (default): where the warm-up is at most a
- * quarter of a workgroup's work and 1024 workgroups remain; 0: never; 1: wherever it can run, with the given chunk count.
+ * quarter of a workgroup's work and 512 workgroups remain; 0: never; 1: wherever it can run, with the given chunk count.
  * Same per-sample arithmetic; start states equal to 1e-22 of the state's size. No reference counterpart. */
 int zmls_iir_set_one_sweep(zmls_iir *f, int mode, int chunks_per_workgroup);
 int zmls_iir_last_fused_form(const zmls_iir *f);

@@ -388,6 +388,18 @@ __global__ void __launch_bounds__(256) iir_once_kernel(const IirDev *__restrict_
     double zt[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) zt[k] = (MODE == 2 && c < n_ch) ? zeta[c * S + k] : 0.0;
+    // interior chunks of float64 data: the next chunk's 32 loads per thread are issued before this chunk's arithmetic and fly through
+    // it (the barriers below wait for LDS only), so the workgroup does not alternate between a memory phase and an LDS phase
+    const bool f64_cols = in_dtype == ZMLS_F64 && c0 + CC <= n_ch;
+    double r[PER];
+    bool pre = q_begin < q_end && f64_cols && (q_begin + 1) * TT <= n_rows;
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * 256, tt = e / CC, cc = e % CC;
+            r[i] = __builtin_nontemporal_load((const double *)x + (q_begin * TT + tt) * rs + (c0 + cc) * cs);
+        }
+    }
     for (int64_t q = q_begin; q < q_end; ++q) {
         const int64_t t0 = q * TT;
         const bool out = q >= q_first;
@@ -398,13 +410,7 @@ __global__ void __launch_bounds__(256) iir_once_kernel(const IirDev *__restrict_
                 for (int i = 0; i < TT * S / 256; ++i) psl[tid + i * 256] = (tid + i * 256 < have) ? psi[t0 * S + tid + i * 256] : 0.0;
             }
         }
-        if (in_dtype == ZMLS_F64 && t0 + TT <= n_rows && c0 + CC <= n_ch) {
-            double r[PER];
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int e = tid + i * 256, tt = e / CC, cc = e % CC;
-                r[i] = __builtin_nontemporal_load((const double *)x + (t0 + tt) * rs + (c0 + cc) * cs);
-            }
+        if (pre) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int e = tid + i * 256, tt = e / CC, cc = e % CC;
@@ -415,6 +421,14 @@ __global__ void __launch_bounds__(256) iir_once_kernel(const IirDev *__restrict_
                 const int tt = e / CC, cc = e % CC;
                 const int64_t t = t0 + tt, ch = c0 + cc;
                 tile[((tt / kIirSub) * CC + cc) * kIirPitch + (tt % kIirSub)] = (t < n_rows && ch < n_ch) ? iir_load(x, t * rs + ch * cs, in_dtype) : 0.0;
+            }
+        }
+        pre = q + 1 < q_end && f64_cols && (q + 2) * TT <= n_rows;
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = tid + i * 256, tt = e / CC, cc = e % CC;
+                r[i] = __builtin_nontemporal_load((const double *)x + (t0 + TT + tt) * rs + (c0 + cc) * cs);
             }
         }
         __syncthreads();                          // the tile, psl and the carried state are in LDS
@@ -494,7 +508,7 @@ int launch_iir_s(const IirDev *d_f, const void *d_x, int in_dtype, int64_t n_row
         for (int mult : {8, 4}) {
             if (M) break;
             const uint64_t m = (uint64_t)std::max(8, mult * nt_once);
-            if (n_cgrp * ((n_chunks + m - 1) / m) >= 1024) { M = (int)m; break; }
+            if (n_cgrp * ((n_chunks + m - 1) / m) >= 512) { M = (int)m; break; }       // 512: two workgroups on every CU at once
         }
         if (M && (xe <= yb || ye <= xb)) {
             const uint64_t blocks = n_cgrp * ((n_chunks + M - 1) / M);
