@@ -19,6 +19,9 @@ f.reserve_fused(p, R * L, C)
 call = lambda: p.impulse_filtered_device(f, x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, h.ptr, C, 1)
 t = Timer(0)
 forms = [int(v) for v in os.environ.get("FORMS", "-1").split(",")]       # FORMS=0,1: the sweep form and the post-filter form (zmls_iir_set_fused_form)
+if os.environ.get("ONCE_M"):                                              # ONCE_M=16: the one-sweep filter forced with that many chunks per workgroup (0: never)
+    m = int(os.environ["ONCE_M"])
+    f.set_one_sweep(1 if m else 0, m)
 for form in forms:
     f.set_fused_form(form)
     call(); sync(0)
