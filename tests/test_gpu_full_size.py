@@ -93,6 +93,51 @@ def test_config3_share_n20_512_channels_16_periods_f64():
     p.close()
 
 
+def test_config3_share_with_deemphasis_in_one_call_both_forms():
+    """MLS_simple.get_impulse's chain (apply_deemphasis + get_impulse, mls.py:401-414, 454-458) on one GPU's share of config 3 with
+    the reference's shelving filter (mls.py:433), through zmls_impulse_filtered_device in its two forms: the filter after the
+    transform (the default at this size) and the one sweep in time order. Sampled channels: the two forms against each other, the
+    known system (its response through the filter, circularly: the filter's memory is a hundredth of a period), and lfilter +
+    oracle on the very capture for the two corner channels."""
+    import scipy.signal
+    from zignal_amd.device import IirFilter
+    from zignal_amd.filters.biquads import RBJ
+    N, C, R = 20, 512, 17
+    p, d_x, d_h = run_batch(N, C, R, "f64", 1e-3)
+    L = p.L
+    B, A = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=96000).get_coefficients()
+    f = IirFilter(A, B, device=0)                                  # de-emphasis: the inverse of the emphasis filter (mls.py:365-366)
+    f.reserve_fused(p, R * L, C)
+    chans = one_per_slab(C) + [0, 511]
+    got = {}
+    for form in (1, 0):
+        f.set_fused_form(form)
+        d_h.fill(0xFF)
+        p.impulse_filtered_device(f, d_x.ptr, p.dtype_code, R * L, C, C, 1, d_h.ptr, C, 1)
+        sync(0)
+        assert f.last_fused_form() == form
+        got[form] = {c: channel(p, d_h, L, C, c) for c in chans}
+    f.set_fused_form(-1)
+    p.impulse_filtered_device(f, d_x.ptr, p.dtype_code, R * L, C, C, 1, d_h.ptr, C, 1)
+    sync(0)
+    assert f.last_fused_form() == 1
+    ref = c_oracle.sequence(N, p.taps)
+    for c in chans:
+        assert np.all(np.isfinite(got[1][c])), c
+        assert rel_err(got[1][c], got[0][c]) <= 1e-13, c
+        e = expected_noise_free(p, c)
+        want = scipy.signal.lfilter(A, B, np.concatenate([e, e]))[L:]          # the periodic steady state = the circular filter
+        assert np.max(np.abs(got[1][c] - want)) <= 1e-4, c
+    for c in (0, 511):
+        x = channel(p, d_x, R * L, C, c)
+        y = scipy.signal.lfilter(A, B, x)
+        assert rel_err(got[1][c], oracle_ir(N, p.taps, y.reshape(-1, 1), ref)) <= 1e-12, c
+    f.close()
+    d_x.free()
+    d_h.free()
+    p.close()
+
+
 def test_config4_n24_256_channels_three_passes_f64():
     N, C, R = 24, 256, 2
     p, d_x, d_h = run_batch(N, C, R, "f64", 0.0)
