@@ -26,7 +26,7 @@ constexpr int kTileBytes = 256;     // bytes of adjacent channels per frame of a
 template <typename T, typename TIN>
 __global__ void __launch_bounds__(256) sum_transpose_kernel(const TIN *__restrict__ x, int64_t L, int periods, int skip, int64_t ch_stride,
                                                             int64_t ch_first, int64_t n_ch_valid, T *__restrict__ S, int64_t Cs,
-                                                            uint32_t n_cblk)
+                                                            uint32_t n_cblk, int64_t j_first /* first frame of this launch */)
 {
     using V = typename LVec<T>::type;
     constexpr int E = LVec<T>::E;
@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) sum_transpose_kernel(const TIN *__restric
     __shared__ T tile[kTileRows][TC + E];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // consecutive workgroups are the channel blocks of one run of frames: together they write whole rows of S
-    const int64_t j0 = (int64_t)(blockIdx.x / n_cblk) * kTileRows;
+    const int64_t j0 = j_first + (int64_t)(blockIdx.x / n_cblk) * kTileRows;
     const int64_t cb = (int64_t)(blockIdx.x % n_cblk) * TC;   // first channel of the tile inside the staging array
     const int64_t j = j0 + lane;
 
@@ -84,6 +84,88 @@ __global__ void __launch_bounds__(256) sum_transpose_kernel(const TIN *__restric
     }
 }
 
+// The same for float64 captures in 16-byte loads (round 3): a lane owns TWO consecutive frames, a tile is 128 frames. A period of an
+// odd length L starts on an odd element every other time, so a lane's pair (j, j+1) is 16-byte aligned only for half of the (channel,
+// period) runs; for the others the lane loads the aligned pair (j+1, j+2) instead and takes frame j from the lane below (lane 0: one
+// 8-byte load). Which of the two is uniform over the wave. Frame j0 + 128 is touched, so only tiles with j0 + 129 <= L run here; the
+// rows after them go through the kernel above. Same additions in the same order: same bits.
+constexpr int kTileRows2 = 128;
+__global__ void __launch_bounds__(256) sum_transpose_pairs_kernel(const double *__restrict__ x, int64_t L, int periods, int skip, int64_t ch_stride,
+                                                                  int64_t ch_first, int64_t n_ch_valid, double *__restrict__ S, int64_t Cs,
+                                                                  uint32_t n_cblk)
+{
+    typedef double D2 __attribute__((ext_vector_type(2)));
+    constexpr int TC = kTileBytes / 8;                   // 32 channels per tile
+    constexpr int CPW = TC / 4;                          // 8 per wave
+    __shared__ double tile[kTileRows2][TC + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j0 = (int64_t)(blockIdx.x / n_cblk) * kTileRows2;
+    const int64_t cb = (int64_t)(blockIdx.x % n_cblk) * TC;
+
+    D2 acc[CPW];
+    int64_t e0[CPW];                                     // element offset of frame j0 of the first summed period, per channel
+    bool ok[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int64_t ch = ch_first + cb + wave * CPW + i;
+        ok[i] = ch < n_ch_valid;
+        e0[i] = (ok[i] ? ch : 0) * ch_stride + (int64_t)skip * L + j0;
+        acc[i] = (D2)0.0;
+    }
+    constexpr int DEPTH = 2;
+    for (int p = 0; p < periods; p += DEPTH) {
+        D2 t[DEPTH][CPW];
+        double lo[DEPTH][CPW];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) {
+                const int64_t e = e0[i] + (int64_t)(p + d) * L;
+                const int64_t par = e & 1;
+                if (p + d < periods) {
+                    t[d][i] = __builtin_nontemporal_load((const D2 *)(x + e + par + 2 * lane));
+                    lo[d][i] = (par && lane == 0) ? __builtin_nontemporal_load(x + e) : 0.0;
+                } else {
+                    t[d][i] = (D2)0.0;
+                    lo[d][i] = 0.0;
+                }
+            }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) {
+                if (p + d >= periods) continue;
+                const int64_t par = (e0[i] + (int64_t)(p + d) * L) & 1;
+                if (par) {
+                    double below = __shfl_up(t[d][i][1], 1, 64);
+                    if (lane == 0) below = lo[d][i];
+                    acc[i][0] += below;                   // period order, as numpy adds the rows
+                    acc[i][1] += t[d][i][0];
+                } else {
+                    acc[i] += t[d][i];
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        tile[2 * lane][wave * CPW + i] = ok[i] ? acc[i][0] : 0.0;
+        tile[2 * lane + 1][wave * CPW + i] = ok[i] ? acc[i][1] : 0.0;
+    }
+    __syncthreads();
+    constexpr int VPR = TC / 2;                          // 16-byte vectors per tile row
+    constexpr int RPP = 256 / VPR;                       // rows per sweep of the workgroup
+    const int vv = threadIdx.x % VPR, r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int r = r0; r < kTileRows2; r += RPP) {
+        if (cb + vv * 2 < Cs) {
+            D2 o;
+            o[0] = tile[r][vv * 2];
+            o[1] = tile[r][vv * 2 + 1];
+            __builtin_nontemporal_store(o, (D2 *)(S + (j0 + r) * Cs + cb + vv * 2));
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict__ H, int64_t L, int64_t Cs, int64_t n_ch, T *__restrict__ out,
                                                             int64_t out_ch_stride, uint32_t n_cblk)
@@ -120,10 +202,22 @@ int launch_sum_transpose_t(const void *d_x, int64_t L, int64_t periods, int skip
                            void *d_S, int64_t Cs, hipStream_t st)
 {
     constexpr int TC = kTileBytes / (int)sizeof(T);
-    const uint64_t n_cblk = (uint64_t)((Cs + TC - 1) / TC), blocks = (uint64_t)((L + kTileRows - 1) / kTileRows) * n_cblk;
+    const uint64_t n_cblk = (uint64_t)((Cs + TC - 1) / TC);
+    int64_t j_first = 0;
+    if constexpr (__is_same(T, double) && __is_same(TIN, double)) {
+        // float64 in and out, 16-byte aligned capture: the tiles of 128 frames that lie wholly before the period's last frame in pairs
+        static const bool pairs_on = [] { const char *v = getenv("ZMLS_SUM_PAIRS"); return !(v && *v == '0'); }();
+        const int64_t n_full = (L - 1) / kTileRows2;
+        if (pairs_on && n_full > 0 && ((uintptr_t)d_x & 15) == 0 && (uint64_t)n_full * n_cblk <= 0x7FFFFFFFull) {
+            hipLaunchKernelGGL(sum_transpose_pairs_kernel, dim3((uint32_t)((uint64_t)n_full * n_cblk)), dim3(256), 0, st, (const double *)d_x, L, (int)periods, skip,
+                               ch_stride, ch_first, n_ch_valid, (double *)d_S, Cs, (uint32_t)n_cblk);
+            j_first = n_full * kTileRows2;
+        }
+    }
+    const uint64_t blocks = (uint64_t)((L - j_first + kTileRows - 1) / kTileRows) * n_cblk;
     if (blocks > 0x7FFFFFFFull) { set_error("layout grid out of range"); return ZMLS_E_ARG; }
     hipLaunchKernelGGL((sum_transpose_kernel<T, TIN>), dim3((uint32_t)blocks), dim3(256), 0, st, (const TIN *)d_x, L, (int)periods, skip, ch_stride,
-                       ch_first, n_ch_valid, (T *)d_S, Cs, (uint32_t)n_cblk);
+                       ch_first, n_ch_valid, (T *)d_S, Cs, (uint32_t)n_cblk, j_first);
     ZHIP(hipGetLastError());
     return ZMLS_OK;
 }
