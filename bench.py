@@ -457,13 +457,14 @@ def next_rows(dev):
     from zignal_amd.filters.biquads import RBJ
     B, A = RBJ(filtertype="highshelf", gaindb=-10, f0=100, Q=0.707, fs=96000).get_coefficients()   # MLS_simple's emphasis filter (mls.py:433)
     f = IirFilter(A, B, device=dev)                              # de-emphasis: its inverse (mls.py:365-366)
-    x = DeviceBuffer(R * L * C * 8, dev); x.fill(0)
+    p = Plan(N, TAPS[N][0], device=dev)
+    p.reserve(C, staging=True)
+    x = DeviceBuffer(R * L * C * 8, dev)
+    p.synth_device(x.ptr, _lib.ZMLS_F64, R, C, C, 1, seed=SEED + 77, sigma=1e-3)      # the headline's kind of capture (a zero-filled one streams ~1 ms faster)
     y = DeviceBuffer(2 * L * C * 8, dev)
     f.reserve(2 * L, C)
     rows["filter_2L_x512_ms"] = timed(lambda: f.filter_device(x.ptr, _lib.ZMLS_F64, 2 * L, C, C, 1, y.ptr, C, 1), 3)
     y.free()
-    p = Plan(N, TAPS[N][0], device=dev)
-    p.reserve(C, staging=True)
     hh = DeviceBuffer(L * C * 8, dev)
     f.reserve_fused(p, R * L, C)
     rows["deemphasis_fused_with_impulse_N20_x512_x17_ms"] = timed(lambda: p.impulse_filtered_device(f, x.ptr, _lib.ZMLS_F64, R * L, C, C, 1, hh.ptr, C, 1), 3)

@@ -12,7 +12,11 @@ N, C, R = 20, 512, 17
 p = Plan(N, TAPS[N][0], device=0)
 L = p.L
 p.reserve(C, staging=True)
-x = DeviceBuffer(R * L * C * 8); x.fill(0)
+x = DeviceBuffer(R * L * C * 8)
+if os.environ.get("SYNTH"):                                               # SYNTH=1: the synthetic capture of bench.py instead of zeros
+    p.synth_device(x.ptr, _lib.ZMLS_F64, R, C, C, 1, seed=7, sigma=1e-3)
+else:
+    x.fill(0)
 h = DeviceBuffer(L * C * 8)
 f = IirFilter([1.0, -1.9, 0.9], [1.2, -1.8, 0.7], device=0)
 f.reserve_fused(p, R * L, C)
