@@ -168,14 +168,14 @@ __global__ void __launch_bounds__(256) sum_transpose_pairs_kernel(const double *
 
 template <typename T>
 __global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict__ H, int64_t L, int64_t Cs, int64_t n_ch, T *__restrict__ out,
-                                                            int64_t out_ch_stride, uint32_t n_cblk)
+                                                            int64_t out_ch_stride, uint32_t n_cblk, int64_t j_first /* first frame of this launch */)
 {
     using V = typename LVec<T>::type;
     constexpr int E = LVec<T>::E;
     constexpr int TC = kTileBytes / (int)sizeof(T);
     constexpr int CPW = TC / 4;
     __shared__ T tile[kTileRows][TC + E];
-    const int64_t j0 = (int64_t)(blockIdx.x / n_cblk) * kTileRows;
+    const int64_t j0 = j_first + (int64_t)(blockIdx.x / n_cblk) * kTileRows;
     const int64_t cb = (int64_t)(blockIdx.x % n_cblk) * TC;
     constexpr int VPR = TC / E;
     constexpr int RPP = 256 / VPR;
@@ -194,6 +194,55 @@ __global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict_
     for (int i = 0; i < CPW; ++i) {
         const int64_t ch = cb + wave * CPW + i;
         if (j < L && ch < n_ch) __builtin_nontemporal_store(tile[lane][wave * CPW + i], out + ch * out_ch_stride + j);
+    }
+}
+
+// The same for float64 responses in 16-byte stores (round 3), whole tiles of 128 frames only: a lane writes frames (j, j+1) of a
+// channel whose run starts on an even element, else (j+1, j+2) - lanes 0..62 - with frames j0 and j0 + 127 as single stores;
+// which of the two is uniform over the wave (channel c starts c * out_ch_stride elements in, and L is odd).
+__global__ void __launch_bounds__(256) transpose_out_pairs_kernel(const double *__restrict__ H, int64_t Cs, int64_t n_ch, double *__restrict__ out,
+                                                                  int64_t out_ch_stride, uint32_t n_cblk)
+{
+    typedef double D2 __attribute__((ext_vector_type(2)));
+    constexpr int TC = kTileBytes / 8;
+    constexpr int CPW = TC / 4;
+    __shared__ double tile[kTileRows2][TC + 2];
+    const int64_t j0 = (int64_t)(blockIdx.x / n_cblk) * kTileRows2;
+    const int64_t cb = (int64_t)(blockIdx.x % n_cblk) * TC;
+    constexpr int VPR = TC / 2;
+    constexpr int RPP = 256 / VPR;
+    const int vv = threadIdx.x % VPR, r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int r = r0; r < kTileRows2; r += RPP) {
+        D2 o = (D2)0.0;
+        if (cb + vv * 2 < Cs) o = __builtin_nontemporal_load((const D2 *)(H + (j0 + r) * Cs + cb + vv * 2));
+        tile[r][vv * 2] = o[0];
+        tile[r][vv * 2 + 1] = o[1];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int64_t ch = cb + wave * CPW + i;
+        if (ch >= n_ch) continue;
+        const int col = wave * CPW + i;
+        double *dst = out + ch * out_ch_stride + j0;
+        if ((((uintptr_t)dst) & 15) == 0) {
+            D2 o;
+            o[0] = tile[2 * lane][col];
+            o[1] = tile[2 * lane + 1][col];
+            __builtin_nontemporal_store(o, (D2 *)(dst + 2 * lane));
+        } else {
+            if (lane < 63) {
+                D2 o;
+                o[0] = tile[2 * lane + 1][col];
+                o[1] = tile[2 * lane + 2][col];
+                __builtin_nontemporal_store(o, (D2 *)(dst + 2 * lane + 1));
+            } else {
+                __builtin_nontemporal_store(tile[127][col], dst + 127);
+            }
+            if (lane == 0) __builtin_nontemporal_store(tile[0][col], dst);
+        }
     }
 }
 
@@ -254,16 +303,26 @@ int launch_transpose_out(const void *d_H, int dtype, int64_t L, int64_t Cs, int6
 {
     if (dtype == ZMLS_F64) {
         constexpr int TC = kTileBytes / 8;
-        const uint64_t n_cblk = (uint64_t)((n_ch + TC - 1) / TC), blocks = (uint64_t)((L + kTileRows - 1) / kTileRows) * n_cblk;
+        const uint64_t n_cblk = (uint64_t)((n_ch + TC - 1) / TC);
+        int64_t j_first = 0;
+        static const bool pairs_on = [] { const char *v = getenv("ZMLS_SUM_PAIRS"); return !(v && *v == '0'); }();
+        const int64_t n_full = L / kTileRows2;
+        if (pairs_on && n_full > 0 && ((uintptr_t)d_out & 7) == 0 && (uint64_t)n_full * n_cblk <= 0x7FFFFFFFull) {
+            hipLaunchKernelGGL(transpose_out_pairs_kernel, dim3((uint32_t)((uint64_t)n_full * n_cblk)), dim3(256), 0, st, (const double *)d_H, Cs, n_ch,
+                               (double *)d_out, out_ch_stride, (uint32_t)n_cblk);
+            j_first = n_full * kTileRows2;
+        }
+        const uint64_t blocks = (uint64_t)((L - j_first + kTileRows - 1) / kTileRows) * n_cblk;
         if (blocks > 0x7FFFFFFFull) { set_error("layout grid out of range"); return ZMLS_E_ARG; }
-        hipLaunchKernelGGL(transpose_out_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, st, (const double *)d_H, L, Cs, n_ch, (double *)d_out,
-                           out_ch_stride, (uint32_t)n_cblk);
+        if (blocks)
+            hipLaunchKernelGGL(transpose_out_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, st, (const double *)d_H, L, Cs, n_ch, (double *)d_out,
+                               out_ch_stride, (uint32_t)n_cblk, j_first);
     } else if (dtype == ZMLS_F32) {
         constexpr int TC = kTileBytes / 4;
         const uint64_t n_cblk = (uint64_t)((n_ch + TC - 1) / TC), blocks = (uint64_t)((L + kTileRows - 1) / kTileRows) * n_cblk;
         if (blocks > 0x7FFFFFFFull) { set_error("layout grid out of range"); return ZMLS_E_ARG; }
         hipLaunchKernelGGL(transpose_out_kernel<float>, dim3((uint32_t)blocks), dim3(256), 0, st, (const float *)d_H, L, Cs, n_ch, (float *)d_out,
-                           out_ch_stride, (uint32_t)n_cblk);
+                           out_ch_stride, (uint32_t)n_cblk, (int64_t)0);
     } else { set_error("responses are f64 or f32"); return ZMLS_E_ARG; }
     ZHIP(hipGetLastError());
     return ZMLS_OK;
