@@ -15,7 +15,7 @@ from gpu_common import G, case_input, load_json, oracle_ir, plan, rel_err
 from oracle import c_oracle, mls_oracle
 from zignal_amd import _lib
 from zignal_amd import _lib as L_
-from zignal_amd.device import DeviceBuffer
+from zignal_amd.device import DeviceBuffer, sync
 from zignal_amd.measure.mls import MLS, TAPS, MLS_simple, _MLS_base
 
 pytestmark = pytest.mark.gpu
@@ -349,6 +349,45 @@ def test_layout_adapters_on_the_device_entry_point(N, C, R, dtype, stage):
     d_h.fill(0xFF)
     p.impulse_device(d_i.ptr, _lib.ZMLS_I16, R * L, C, C, 1, d_h.ptr, C, 1)
     assert rel_err(d_h.download((L, C), npdt), want_i) <= tol
+    p.close()
+
+
+@pytest.mark.parametrize("N,C,R,pad", [(11, 33, 3, 0), (12, 40, 4, 1), (12, 16, 2, 3), (13, 64, 5, 2), (14, 48, 3, 1)])
+def test_stacked_float64_captures_at_every_alignment(N, C, R, pad):
+    """round 3 (layout.hip, sum_transpose_pairs_kernel / transpose_out_pairs_kernel): stacked float64 captures are summed in 16-byte
+    loads and stacked responses written in 16-byte stores, with the odd-started runs (L is odd) shifted by one frame. Buffers that
+    start 8 bytes off a 16-byte boundary and captures with `pad` unused samples between them must give the very same responses."""
+    from zignal_amd.device import Plan
+    taps = TAPS[N][0]
+    L = (1 << N) - 1
+    rng = np.random.default_rng(N * 11 + C)
+    x = rng.standard_normal((R * L, C))
+    ref = c_oracle.sequence(N, taps)
+    want = np.stack([oracle_ir(N, taps, np.ascontiguousarray(x[:, c:c + 1]), ref) for c in range(C)], axis=1)
+    p = Plan(N, taps, device=0)
+    p.reserve(C)
+    L_.check(L_.lib().zmls_plan_reserve_staging(p._h, C))
+    stride = R * L + pad
+    results = []
+    for off_in in (0, 1):
+        for off_out in (0, 1):
+            host = np.full(off_in + C * stride, np.nan)
+            for c in range(C):
+                host[off_in + c * stride: off_in + c * stride + R * L] = x[:, c]
+            d_x = DeviceBuffer(host.nbytes).upload(host)
+            d_h = DeviceBuffer((off_out + C * L) * 8)
+            d_h.fill(0xFF)
+            p.impulse_device(d_x.ptr + 8 * off_in, p.dtype_code, R * L, C, 1, stride, d_h.ptr + 8 * off_out, 1, L)
+            sync(0)
+            out = d_h.download((off_out + C * L,), np.float64)
+            if off_out:
+                assert np.isnan(out[0])                      # 0xFF fill: the element before the first response is untouched
+            h = out[off_out:].reshape(C, L).T
+            assert rel_err(h, want) <= TOL64
+            results.append(h)
+            d_x.free(); d_h.free()
+    for h in results[1:]:
+        assert np.array_equal(h, results[0])
     p.close()
 
 
